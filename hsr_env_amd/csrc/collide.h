@@ -1,0 +1,440 @@
+// Kinematics + collision kernels (fp32, one lane per env; collision: one wave per (64 envs, pair)).
+//
+// Reference path replaced: the position stage of mj_step reached through `self.sim.step()`
+// (hsr/env.py:123): mj_kinematics and mj_collision.
+#pragma once
+#include "devmath.h"
+#include "model.h"
+
+// ------------------------------------------------------------------ kinematics (a-2.1)
+__global__ void k_kinematics(DevModel m, DevState s) {
+    int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= s.N) return;
+    if (s.done[e]) return;
+    const int N = s.N;
+    View qpos{s.qpos + e, N}, xpos{s.xpos + e, N}, xmat{s.xmat + e, N};
+    View ang{s.dof_ang + e, N}, lin{s.dof_lin + e, N}, anc{s.dof_anchor + e, N};
+    m3 I;
+#pragma unroll
+    for (int k = 0; k < 9; k++) I.a[k] = (k % 4 == 0) ? 1.f : 0.f;
+    xpos.set3(0, mk3(0, 0, 0));
+    xmat.setm(0, I);
+    for (int l = 1; l < m.nlink; l++) {
+        v3 pos;
+        m3 mat;
+        const int d0 = m.link_dofadr[l], dn = m.link_dofnum[l];
+        if (m.link_free[l]) {
+            const int a = m.link_qposadr[l];
+            pos = mk3(qpos[a], qpos[a + 1], qpos[a + 2]);
+            q4 q;
+            q.w = qpos[a + 3]; q.x = qpos[a + 4]; q.y = qpos[a + 5]; q.z = qpos[a + 6];
+            q = qnormalized(q);                                  // mj_kinematics normalises in place
+            qpos[a + 3] = q.w; qpos[a + 4] = q.x; qpos[a + 5] = q.y; qpos[a + 6] = q.z;
+            mat = q2m(q);
+            for (int k = 0; k < 3; k++) {
+                lin.set3(d0 + k, mk3(k == 0, k == 1, k == 2));
+                ang.set3(d0 + k, mk3(0, 0, 0));
+                anc.set3(d0 + k, pos);
+                ang.set3(d0 + 3 + k, col(mat, k));
+                lin.set3(d0 + 3 + k, mk3(0, 0, 0));
+                anc.set3(d0 + 3 + k, pos);
+            }
+        } else {
+            const int p = m.link_parent[l];
+            const m3 Rp = xmat.getm(p);
+            pos = xpos.get3(p) + mulmv(Rp, ld3(m.link_pos, l));
+            mat = mulmm(Rp, ldm(m.link_mat, l));
+            for (int k = d0; k < d0 + dn; k++) {
+                const float q = qpos[m.dof_qposadr[k]];
+                const v3 ax = ld3(m.dof_axis, k);
+                if (m.dof_type[k] == DOF_SLIDE) {
+                    pos = pos + mulmv(mat, ax) * q;
+                } else {
+                    const v3 jp = ld3(m.dof_pos, k);
+                    const v3 anchor = pos + mulmv(mat, jp);
+                    float sn, cs;
+                    sincosf(0.5f * q, &sn, &cs);
+                    q4 qr;
+                    qr.w = cs; qr.x = ax.x * sn; qr.y = ax.y * sn; qr.z = ax.z * sn;
+                    mat = mulmm(mat, q2m(qr));
+                    pos = anchor - mulmv(mat, jp);
+                }
+            }
+            for (int k = d0; k < d0 + dn; k++) {
+                const v3 ax = mulmv(mat, ld3(m.dof_axis, k));
+                if (m.dof_type[k] == DOF_SLIDE) {
+                    lin.set3(k, ax); ang.set3(k, mk3(0, 0, 0)); anc.set3(k, pos);
+                } else {
+                    ang.set3(k, ax); lin.set3(k, mk3(0, 0, 0)); anc.set3(k, pos + mulmv(mat, ld3(m.dof_pos, k)));
+                }
+            }
+        }
+        xpos.set3(l, pos);
+        xmat.setm(l, mat);
+    }
+}
+
+// ------------------------------------------------------------------ collision (a-2.3)
+struct Geom {
+    int type, nvert;
+    v3 pos, size;
+    m3 mat;
+    const float *verts;
+};
+
+__device__ __forceinline__ Geom load_geom(const DevModel &m, const DevState &s, int g, int e) {
+    Geom G;
+    const int l = m.geom_link[g];
+    View xpos{s.xpos + e, s.N}, xmat{s.xmat + e, s.N};
+    const m3 R = xmat.getm(l);
+    G.pos = xpos.get3(l) + mulmv(R, ld3(m.geom_pos, g));
+    G.mat = mulmm(R, ldm(m.geom_mat, g));
+    G.type = m.geom_type[g];
+    G.size = ld3(m.geom_size, g);
+    G.verts = m.mesh_vert + 3 * m.geom_meshadr[g];
+    G.nvert = m.geom_meshnum[g];
+    return G;
+}
+
+// support point of a convex geom in world direction dir (ties resolved as in the oracle)
+__device__ __forceinline__ v3 support(const Geom &G, v3 dir) {
+    const v3 dl = mulmtv(G.mat, dir);
+    v3 loc;
+    if (G.type == GEOM_BOX) {
+        loc = mk3(dl.x > 0 ? G.size.x : -G.size.x, dl.y > 0 ? G.size.y : -G.size.y, dl.z > 0 ? G.size.z : -G.size.z);
+    } else if (G.type == GEOM_CYLINDER) {
+        const float rr = sqrtf(dl.x * dl.x + dl.y * dl.y);
+        if (rr > HSR_MINVAL) { loc.x = dl.x / rr * G.size.x; loc.y = dl.y / rr * G.size.x; } else { loc.x = 0; loc.y = 0; }
+        loc.z = dl.z > 0 ? G.size.y : -G.size.y;
+    } else if (G.type == GEOM_SPHERE) {
+        loc = normalized(dl) * G.size.x;
+    } else {
+        // mesh hull: vertex table is wave-uniform (pair index = blockIdx.y) -> scalar loads
+        float bd = -3.0e38f;
+        loc = mk3(0, 0, 0);
+        for (int i = 0; i < G.nvert; i++) {
+            const v3 v = ld3(G.verts, i);
+            const float t = dot(v, dl);
+            if (t > bd) { bd = t; loc = v; }
+        }
+    }
+    return mulmv(G.mat, loc) + G.pos;
+}
+
+struct ContactOut {
+    View con;      // slot-major contact records of this env
+    int slot, cnt, maxcnt;
+    __device__ __forceinline__ void add(v3 pos, v3 n, float dist) {
+        if (cnt >= maxcnt) return;
+        const int b = (slot + cnt) * 7;
+        con[b] = pos.x; con[b + 1] = pos.y; con[b + 2] = pos.z;
+        con[b + 3] = n.x; con[b + 4] = n.y; con[b + 5] = n.z; con[b + 6] = dist;
+        cnt++;
+    }
+};
+
+// --- mjc_PlaneBox: corners below the plane, at most 4
+__device__ __forceinline__ void collide_plane_box(const Geom &P, const Geom &B, ContactOut &out) {
+    const v3 n = col(P.mat, 2);
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const v3 loc = mk3((i & 1) ? B.size.x : -B.size.x, (i & 2) ? B.size.y : -B.size.y, (i & 4) ? B.size.z : -B.size.z);
+        const v3 c = mulmv(B.mat, loc) + B.pos;
+        const float dist = dot(c - P.pos, n);
+        if (dist < 0 && out.cnt < 4) out.add(c - n * (0.5f * dist), n, dist);
+    }
+}
+
+// --- mjc_PlaneConvex restated with the deepest support point only
+__device__ __forceinline__ void collide_plane_convex(const Geom &P, const Geom &Cx, ContactOut &out) {
+    const v3 n = col(P.mat, 2);
+    const v3 p = support(Cx, -n);
+    const float dist = dot(p - P.pos, n);
+    if (dist < 0) out.add(p - n * (0.5f * dist), n, dist);
+}
+
+// --- box-box: SAT + reference-face clipping; polygon scratch lives in LDS ([buf][vertex][xyz][lane])
+#define POLY(buf, i, k) poly[(((buf) * 8 + (i)) * 3 + (k)) * 64 + lane]
+__device__ __forceinline__ int clip_poly(float *poly, int lane, int src, int n, v3 axis, float lim, v3 origin) {
+    const int dst = src ^ 1;
+    int no = 0;
+    for (int i = 0; i < n; i++) {
+        const int i2 = (i + 1 == n) ? 0 : i + 1;
+        const v3 a = mk3(POLY(src, i, 0), POLY(src, i, 1), POLY(src, i, 2));
+        const v3 b = mk3(POLY(src, i2, 0), POLY(src, i2, 1), POLY(src, i2, 2));
+        const float da = dot(a - origin, axis) - lim, db = dot(b - origin, axis) - lim;
+        if (da <= 0 && no < 8) { POLY(dst, no, 0) = a.x; POLY(dst, no, 1) = a.y; POLY(dst, no, 2) = a.z; no++; }
+        if (((da < 0 && db > 0) || (da > 0 && db < 0)) && no < 8) {
+            const float t = da / (da - db);
+            POLY(dst, no, 0) = a.x + t * (b.x - a.x); POLY(dst, no, 1) = a.y + t * (b.y - a.y); POLY(dst, no, 2) = a.z + t * (b.z - a.z);
+            no++;
+        }
+    }
+    return no;
+}
+
+__device__ void collide_box_box(const Geom &G1, const Geom &G2, ContactOut &out, float *poly, int lane) {
+    v3 A[3], B[3];
+    float s1[3] = {G1.size.x, G1.size.y, G1.size.z}, s2[3] = {G2.size.x, G2.size.y, G2.size.z};
+#pragma unroll
+    for (int i = 0; i < 3; i++) { A[i] = col(G1.mat, i); B[i] = col(G2.mat, i); }
+    const v3 dv = G2.pos - G1.pos;
+    float C[3][3], aC[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) { C[i][j] = dot(A[i], B[j]); aC[i][j] = fabsf(C[i][j]); }
+    float best = -3.0e38f;
+    int code = -1;
+    v3 bestn = mk3(0, 0, 0);
+    bool sepfound = false;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        const float t = dot(dv, A[i]);
+        const float sep = fabsf(t) - (s1[i] + s2[0] * aC[i][0] + s2[1] * aC[i][1] + s2[2] * aC[i][2]);
+        if (sep > 0) sepfound = true;
+        if (sep > best) { best = sep; code = i; bestn = A[i] * (t < 0 ? -1.f : 1.f); }
+    }
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        const float t = dot(dv, B[j]);
+        const float sep = fabsf(t) - (s2[j] + s1[0] * aC[0][j] + s1[1] * aC[1][j] + s1[2] * aC[2][j]);
+        if (sep > 0) sepfound = true;
+        if (sep > best) { best = sep; code = 3 + j; bestn = B[j] * (t < 0 ? -1.f : 1.f); }
+    }
+    if (sepfound) return;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            v3 L = cross(A[i], B[j]);
+            const float ln = norm(L);
+            if (ln < 1e-6f) continue;
+            L = L * (1.0f / ln);
+            const float t = dot(dv, L);
+            float ra = 0, rb = 0;
+#pragma unroll
+            for (int k = 0; k < 3; k++) { ra += s1[k] * fabsf(dot(A[k], L)); rb += s2[k] * fabsf(dot(B[k], L)); }
+            const float sep = fabsf(t) - (ra + rb);
+            if (sep > 0) sepfound = true;
+            if (sep * 1.05f > best + 1e-9f) { best = sep; code = 6 + 3 * i + j; bestn = L * (t < 0 ? -1.f : 1.f); }
+        }
+    if (sepfound) return;
+    if (code < 6) {
+        const bool ref1 = code < 3;
+        const int ax = ref1 ? code : code - 3;
+        const v3 pr = ref1 ? G1.pos : G2.pos, pi = ref1 ? G2.pos : G1.pos;
+        v3 Ar[3], Ai[3];
+        float sr[3], si[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) { Ar[k] = ref1 ? A[k] : B[k]; Ai[k] = ref1 ? B[k] : A[k]; sr[k] = ref1 ? s1[k] : s2[k]; si[k] = ref1 ? s2[k] : s1[k]; }
+        const v3 nref = bestn * (ref1 ? 1.f : -1.f);
+        int jx = 0;
+        float bd = -1.f;
+#pragma unroll
+        for (int j = 0; j < 3; j++) { const float t = fabsf(dot(nref, Ai[j])); if (t > bd) { bd = t; jx = j; } }
+        // select axes without dynamic register indexing
+        const v3 Aj = jx == 0 ? Ai[0] : (jx == 1 ? Ai[1] : Ai[2]);
+        const v3 Aj1 = jx == 0 ? Ai[1] : (jx == 1 ? Ai[2] : Ai[0]);
+        const v3 Aj2 = jx == 0 ? Ai[2] : (jx == 1 ? Ai[0] : Ai[1]);
+        const float sj = jx == 0 ? si[0] : (jx == 1 ? si[1] : si[2]);
+        const float sj1 = jx == 0 ? si[1] : (jx == 1 ? si[2] : si[0]);
+        const float sj2 = jx == 0 ? si[2] : (jx == 1 ? si[0] : si[1]);
+        const float sgn = dot(nref, Aj) > 0 ? -1.f : 1.f;
+        const v3 fc = pi + Aj * (sgn * sj);
+        const float sg[4][2] = {{1, 1}, {-1, 1}, {-1, -1}, {1, -1}};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const v3 v = fc + Aj1 * (sg[k][0] * sj1) + Aj2 * (sg[k][1] * sj2);
+            POLY(0, k, 0) = v.x; POLY(0, k, 1) = v.y; POLY(0, k, 2) = v.z;
+        }
+        const v3 Au = ax == 0 ? Ar[1] : (ax == 1 ? Ar[2] : Ar[0]);
+        const v3 Av = ax == 0 ? Ar[2] : (ax == 1 ? Ar[0] : Ar[1]);
+        const float su = ax == 0 ? sr[1] : (ax == 1 ? sr[2] : sr[0]);
+        const float sv = ax == 0 ? sr[2] : (ax == 1 ? sr[0] : sr[1]);
+        const float sa = ax == 0 ? sr[0] : (ax == 1 ? sr[1] : sr[2]);
+        int np = 4, buf = 0;
+        np = clip_poly(poly, lane, buf, np, Au, su, pr); buf ^= 1;
+        if (np) { np = clip_poly(poly, lane, buf, np, -Au, su, pr); buf ^= 1; }
+        if (np) { np = clip_poly(poly, lane, buf, np, Av, sv, pr); buf ^= 1; }
+        if (np) { np = clip_poly(poly, lane, buf, np, -Av, sv, pr); buf ^= 1; }
+        for (int k = 0; k < np; k++) {
+            const v3 v = mk3(POLY(buf, k, 0), POLY(buf, k, 1), POLY(buf, k, 2));
+            const float dist = dot(v - pr, nref) - sa;
+            if (dist < 0) out.add(v - nref * (0.5f * dist), bestn, dist);
+        }
+    } else {
+        const int i = (code - 6) / 3, j = (code - 6) % 3;
+        v3 pa = G1.pos, pb = G2.pos;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            if (k != i) pa = pa + A[k] * ((dot(bestn, A[k]) > 0 ? 1.f : -1.f) * s1[k]);
+            if (k != j) pb = pb + B[k] * ((dot(bestn, B[k]) > 0 ? -1.f : 1.f) * s2[k]);
+        }
+        const v3 Ai_ = i == 0 ? A[0] : (i == 1 ? A[1] : A[2]);
+        const v3 Bj_ = j == 0 ? B[0] : (j == 1 ? B[1] : B[2]);
+        const v3 w = pa - pb;
+        const float b = dot(Ai_, Bj_), dd = dot(Ai_, w), ee = dot(Bj_, w), den = 1.f - b * b;
+        const float t = den > 1e-12f ? (b * ee - dd) / den : 0.f, uu = den > 1e-12f ? (ee - b * dd) / den : 0.f;
+        const v3 qa = pa + Ai_ * t, qb = pb + Bj_ * uu;
+        out.add((qa + qb) * 0.5f, bestn, best);
+    }
+}
+#undef POLY
+
+// --- convex-convex: Minkowski Portal Refinement (libccd ccdMPRPenetration as used by mjc_Convex)
+struct Sup { v3 v, v1, v2; };
+__device__ __forceinline__ Sup mpr_support(const Geom &G1, const Geom &G2, v3 dir) {
+    Sup s;
+    s.v1 = support(G1, dir);
+    s.v2 = support(G2, -dir);
+    s.v = s.v1 - s.v2;
+    return s;
+}
+__device__ __forceinline__ float point_seg_dist2(v3 x0, v3 b, v3 &wit) {   // P = origin
+    const v3 d = b - x0;
+    const float t = -dot(x0, d) / dot(d, d);
+    if (t < 0 || fabsf(t) < 1e-30f) wit = x0;
+    else if (t >= 1) wit = b;
+    else wit = x0 + d * t;
+    return dot(wit, wit);
+}
+// libccd's ccdVec3PointTriDist2 for P = origin.  fp32 note: libccd's expanded quadratic form
+// s^2 v + t^2 w + 2 s t r + 2 s p + 2 t q + u cancels catastrophically in fp32 (u ~ 0.1, result ~ 1e-8),
+// so the interior case only reports `interior` and the caller measures the depth along the portal normal.
+__device__ __forceinline__ float point_tri_dist2(v3 x0, v3 B, v3 Cc, v3 &wit, bool &interior) {
+    const v3 d1 = B - x0, d2 = Cc - x0, a = x0;
+    const float v = dot(d1, d1), w = dot(d2, d2), p = dot(a, d1), q = dot(a, d2), r = dot(d1, d2);
+    const float den = w * v - r * r;
+    float sx = -1, t = -1;
+    interior = false;
+    if (fabsf(den) > 0) { sx = (q * r - w * p) / den; t = (-sx * r - q) / w; }
+    if (sx >= 0 && sx <= 1 && t >= 0 && t <= 1 && t + sx <= 1) {
+        wit = x0 + d1 * sx + d2 * t;
+        interior = true;
+        return dot(wit, wit);
+    }
+    v3 w2;
+    float best = point_seg_dist2(x0, B, wit);
+    float dist = point_seg_dist2(x0, Cc, w2);
+    if (dist < best) { best = dist; wit = w2; }
+    dist = point_seg_dist2(B, Cc, w2);
+    if (dist < best) { best = dist; wit = w2; }
+    return best;
+}
+__device__ __forceinline__ v3 portal_dir(const Sup &p1, const Sup &p2, const Sup &p3) {
+    return normalized(cross(p2.v - p1.v, p3.v - p1.v));
+}
+__device__ __forceinline__ void expand_portal(const Sup &p0, Sup &p1, Sup &p2, Sup &p3, const Sup &v4) {
+    const v3 v4v0 = cross(v4.v, p0.v);
+    if (dot(p1.v, v4v0) > 0) { if (dot(p2.v, v4v0) > 0) p1 = v4; else p3 = v4; }
+    else { if (dot(p3.v, v4v0) > 0) p2 = v4; else p1 = v4; }
+}
+__device__ __forceinline__ bool reach_tol(const Sup &p1, const Sup &p2, const Sup &p3, const Sup &v4, v3 dir, float tol) {
+    const float dv4 = dot(v4.v, dir);
+    const float mn = fminf(fminf(dv4 - dot(p1.v, dir), dv4 - dot(p2.v, dir)), dv4 - dot(p3.v, dir));
+    return mn < tol;
+}
+
+__device__ bool mpr_penetration(const Geom &G1, const Geom &G2, float tol, int maxit, float &depth, v3 &dirout, v3 &pos) {
+    const float eps = HSR_EPS;
+    Sup p0, p1, p2, p3, v4;
+    p0.v1 = G1.pos; p0.v2 = G2.pos; p0.v = p0.v1 - p0.v2;
+    if (fabsf(p0.v.x) < eps && fabsf(p0.v.y) < eps && fabsf(p0.v.z) < eps) p0.v.x += 1e-5f;
+    v3 dir = normalized(-p0.v);
+    p1 = mpr_support(G1, G2, dir);
+    if (dot(p1.v, dir) < eps) return false;
+    dir = cross(p0.v, p1.v);
+    if (dot(dir, dir) < eps * eps) {
+        const float l1 = norm(p1.v);
+        if (l1 < eps) return false;
+        depth = l1; dirout = normalized(p1.v); pos = (p1.v1 + p1.v2) * 0.5f;
+        return true;
+    }
+    dir = normalized(dir);
+    p2 = mpr_support(G1, G2, dir);
+    if (dot(p2.v, dir) < eps) return false;
+    dir = normalized(cross(p1.v - p0.v, p2.v - p0.v));
+    if (dot(dir, p0.v) > 0) { const Sup t = p1; p1 = p2; p2 = t; dir = -dir; }
+    for (int it = 0;; it++) {
+        if (it > 100) return false;
+        p3 = mpr_support(G1, G2, dir);
+        if (dot(p3.v, dir) < eps) return false;
+        bool cont = false;
+        if (dot(cross(p1.v, p3.v), p0.v) < -eps) { p2 = p3; cont = true; }
+        if (!cont && dot(cross(p3.v, p2.v), p0.v) < -eps) { p1 = p3; cont = true; }
+        if (!cont) break;
+        dir = normalized(cross(p1.v - p0.v, p2.v - p0.v));
+    }
+    for (int it = 0;; it++) {
+        dir = portal_dir(p1, p2, p3);
+        if (dot(dir, p1.v) >= -eps) break;
+        v4 = mpr_support(G1, G2, dir);
+        if (dot(v4.v, dir) < -eps || reach_tol(p1, p2, p3, v4, dir, tol) || it > maxit) return false;
+        expand_portal(p0, p1, p2, p3, v4);
+    }
+    for (int it = 0;; it++) {
+        dir = portal_dir(p1, p2, p3);
+        v4 = mpr_support(G1, G2, dir);
+        if (reach_tol(p1, p2, p3, v4, dir, tol) || it > maxit) {
+            v3 pdir;
+            bool interior;
+            depth = sqrtf(point_tri_dist2(p1.v, p2.v, p3.v, pdir, interior));
+            if (interior) {
+                // the witness is the foot of the perpendicular: depth = |n . v1|, direction = +-n
+                const float dn = dot(dir, p1.v);
+                depth = fabsf(dn);
+                dirout = dn >= 0 ? dir : -dir;
+            } else {
+                if (fabsf(pdir.x) < eps && fabsf(pdir.y) < eps && fabsf(pdir.z) < eps) pdir = dir;
+                dirout = normalized(pdir);
+            }
+            // mpr_find_pos
+            float b0 = dot(cross(p1.v, p2.v), p3.v), b1 = dot(cross(p3.v, p2.v), p0.v);
+            float b2 = dot(cross(p0.v, p1.v), p3.v), b3 = dot(cross(p2.v, p1.v), p0.v);
+            float sum = b0 + b1 + b2 + b3;
+            if (sum <= 0) {
+                b0 = 0; b1 = dot(cross(p2.v, p3.v), dir); b2 = dot(cross(p3.v, p1.v), dir); b3 = dot(cross(p1.v, p2.v), dir);
+                sum = b1 + b2 + b3;
+            }
+            const float inv = 0.5f / sum;
+            pos = (p0.v1 * b0 + p1.v1 * b1 + p2.v1 * b2 + p3.v1 * b3 + p0.v2 * b0 + p1.v2 * b1 + p2.v2 * b2 + p3.v2 * b3) * inv;
+            return true;
+        }
+        expand_portal(p0, p1, p2, p3, v4);
+    }
+}
+
+// one wave per (64 envs, candidate pair): pair index blockIdx.y is wave-uniform, so the narrowphase
+// function, geom constants and mesh vertex tables are scalar data; lanes differ only in env state.
+__global__ void __launch_bounds__(64) k_collide(DevModel m, DevState s) {
+    __shared__ float poly[2 * 8 * 3 * 64];
+    const int lane = threadIdx.x;
+    const int e = blockIdx.x * 64 + lane;
+    const int p = blockIdx.y;
+    if (e >= s.N) return;
+    if (s.done[e]) return;
+    const int N = s.N;
+    const int g1 = m.pair_geom1[p], g2 = m.pair_geom2[p];
+    const Geom G1 = load_geom(m, s, g1, e), G2 = load_geom(m, s, g2, e);
+    ContactOut out;
+    out.con = View{s.con + e, N};
+    out.slot = m.pair_slot[p];
+    out.maxcnt = m.pair_slot[p + 1] - m.pair_slot[p];
+    out.cnt = 0;
+    // mj_collideGeoms bounding test (margin 0)
+    bool pass;
+    if (G1.type == GEOM_PLANE) pass = dot(G2.pos - G1.pos, col(G1.mat, 2)) <= m.geom_rbound[g2];
+    else { const v3 r = G2.pos - G1.pos; const float b = m.geom_rbound[g1] + m.geom_rbound[g2]; pass = dot(r, r) <= b * b; }
+    if (pass) {
+        const int fn = m.pair_fn[p];
+        if (fn == FN_PLANE_BOX) collide_plane_box(G1, G2, out);
+        else if (fn == FN_PLANE_CONVEX) collide_plane_convex(G1, G2, out);
+        else if (fn == FN_BOX_BOX) collide_box_box(G1, G2, out, poly, lane);
+        else {
+            float depth; v3 dir, pos;
+            if (mpr_penetration(G1, G2, m.mpr_tolerance, m.mpr_iterations, depth, dir, pos)) out.add(pos, dir, -depth);
+        }
+    }
+    s.ncon_pair[(size_t)p * N + e] = out.cnt;
+}

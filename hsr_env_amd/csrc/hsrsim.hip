@@ -1,0 +1,610 @@
+// libhsrsim.so - host side of the C-ABI declared in include/hsrsim.h (gfx950 only).
+//
+// Owns: model tables on the device (fp32), per-batch SoA state, one HIP stream per batch, the
+// substep loop (3 kernels per substep, optionally replayed from a captured hipGraph).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "../../include/hsrsim.h"
+#include "collide.h"
+#include "model.h"
+#include "solve.h"
+
+static thread_local char g_err[512] = "";
+static int fail(int code, const char *fmt, const char *detail = "") {
+    snprintf(g_err, sizeof g_err, fmt, detail);
+    return code;
+}
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(HSR_EDEVICE, "HIP error: %s", hipGetErrorString(e_)); } while (0)
+
+extern "C" const char *hsr_last_error(void) { return g_err; }
+
+// ------------------------------------------------------------------ blob parsing
+struct BlobEntry { char name[32]; uint32_t dtype, ndim, shape[4]; uint64_t off, nbytes; };
+
+struct hsr_model {
+    std::vector<uint8_t> raw;
+    std::map<std::string, const BlobEntry *> entries;
+    const uint8_t *data = nullptr;
+    std::string json;
+    int sizes[16];
+    double opt[16];
+    std::vector<std::string> body_names, joint_names;
+    std::vector<std::pair<int, int>> joint_qposadr;
+    // host copies used to build device tables for each batch's device
+    std::vector<float> ctrlrange, qpos0;
+
+    const double *f64(const char *n, size_t *count = nullptr) const {
+        auto it = entries.find(n);
+        if (it == entries.end()) return nullptr;
+        if (count) *count = it->second->nbytes / 8;
+        return (const double *)(data + it->second->off);
+    }
+    const int *i32(const char *n, size_t *count = nullptr) const {
+        auto it = entries.find(n);
+        if (it == entries.end()) return nullptr;
+        if (count) *count = it->second->nbytes / 4;
+        return (const int *)(data + it->second->off);
+    }
+};
+
+// minimal JSON helpers for the "names"/"meta" sidecar (flat lists of strings / int pairs)
+static size_t json_find_key(const std::string &js, const char *key, size_t from = 0) {
+    std::string k = std::string("\"") + key + "\":";
+    return js.find(k, from);
+}
+static std::vector<std::string> json_string_list(const std::string &js, size_t pos) {
+    std::vector<std::string> out;
+    size_t lb = js.find('[', pos);
+    if (lb == std::string::npos) return out;
+    size_t i = lb + 1;
+    while (i < js.size() && js[i] != ']') {
+        if (js[i] == '"') {
+            size_t j = js.find('"', i + 1);
+            out.push_back(js.substr(i + 1, j - i - 1));
+            i = j + 1;
+        } else if (js.compare(i, 4, "null") == 0) { out.push_back(""); i += 4; }
+        else i++;
+    }
+    return out;
+}
+static std::vector<std::pair<int, int>> json_pair_list(const std::string &js, size_t pos) {
+    std::vector<std::pair<int, int>> out;
+    size_t lb = js.find('[', pos);
+    if (lb == std::string::npos) return out;
+    size_t i = lb + 1;
+    int depth = 1;
+    std::vector<int> cur;
+    while (i < js.size() && depth > 0) {
+        char ch = js[i];
+        if (ch == '[') { depth++; cur.clear(); i++; }
+        else if (ch == ']') { depth--; if (depth == 1 && cur.size() == 2) out.push_back({cur[0], cur[1]}); i++; }
+        else if ((ch >= '0' && ch <= '9') || ch == '-') { char *endp; long v = strtol(js.c_str() + i, &endp, 10); cur.push_back((int)v); i = endp - js.c_str(); }
+        else i++;
+    }
+    return out;
+}
+
+extern "C" int hsr_model_load(const void *blob, size_t len, hsr_model **out) {
+    if (!blob || !out) return fail(HSR_EINVAL, "null argument");
+    if (len < 16 || memcmp(blob, "HSRM0001", 8) != 0) return fail(HSR_EBLOB, "not an HSRM0001 model blob");
+    hsr_model *m = new hsr_model();
+    m->raw.assign((const uint8_t *)blob, (const uint8_t *)blob + len);
+    const uint8_t *raw = m->raw.data();
+    uint32_t n = *(const uint32_t *)(raw + 8);
+    const BlobEntry *ent = (const BlobEntry *)(raw + 16);
+    const uint8_t *p = raw + 16 + (size_t)n * sizeof(BlobEntry);
+    uint64_t jl = *(const uint64_t *)p;
+    m->json.assign((const char *)p + 8, (size_t)jl);
+    m->data = p + 8 + jl;
+    for (uint32_t i = 0; i < n; i++) m->entries[std::string(ent[i].name, strnlen(ent[i].name, 32))] = &ent[i];
+    const int *sz = m->i32("sizes");
+    const double *op = m->f64("opt");
+    if (!sz || !op) { delete m; return fail(HSR_EBLOB, "blob lacks sizes/opt"); }
+    memcpy(m->sizes, sz, sizeof m->sizes);
+    memcpy(m->opt, op, sizeof m->opt);
+    size_t np = json_find_key(m->json, "names");
+    if (np != std::string::npos) {
+        size_t bp = json_find_key(m->json, "body", np), jp = json_find_key(m->json, "joint", np);
+        if (bp != std::string::npos) m->body_names = json_string_list(m->json, bp);
+        if (jp != std::string::npos) m->joint_names = json_string_list(m->json, jp);
+    }
+    size_t qp = json_find_key(m->json, "joint_qposadr");
+    if (qp != std::string::npos) m->joint_qposadr = json_pair_list(m->json, qp);
+    const int nu = m->sizes[HSR_NU], nq = m->sizes[HSR_NQ];
+    const double *cr = m->f64("act_ctrlrange"), *q0 = m->f64("qpos0");
+    m->ctrlrange.resize((size_t)nu * 2);
+    for (int i = 0; i < nu * 2; i++) m->ctrlrange[i] = (float)cr[i];
+    m->qpos0.resize(nq);
+    for (int i = 0; i < nq; i++) m->qpos0[i] = (float)q0[i];
+    *out = m;
+    return HSR_OK;
+}
+extern "C" void hsr_model_destroy(hsr_model *m) { delete m; }
+extern "C" int hsr_model_size(const hsr_model *m, int which) { return (m && which >= 0 && which < 16) ? m->sizes[which] : HSR_EINVAL; }
+extern "C" double hsr_model_timestep(const hsr_model *m) { return m->opt[0]; }
+extern "C" int hsr_model_ctrlrange(const hsr_model *m, float *out) { memcpy(out, m->ctrlrange.data(), m->ctrlrange.size() * sizeof(float)); return HSR_OK; }
+extern "C" int hsr_model_qpos0(const hsr_model *m, float *out) { memcpy(out, m->qpos0.data(), m->qpos0.size() * sizeof(float)); return HSR_OK; }
+extern "C" int hsr_model_body_id(const hsr_model *m, const char *name) {
+    for (size_t i = 0; i < m->body_names.size(); i++) if (m->body_names[i] == name) return (int)i;
+    return fail(HSR_ENAME, "unknown body '%s'", name);
+}
+extern "C" int hsr_model_joint_qpos_addr(const hsr_model *m, const char *name, int *start, int *end) {
+    for (size_t i = 0; i < m->joint_names.size() && i < m->joint_qposadr.size(); i++)
+        if (m->joint_names[i] == name) { *start = m->joint_qposadr[i].first; *end = m->joint_qposadr[i].first + m->joint_qposadr[i].second; return HSR_OK; }
+    return fail(HSR_ENAME, "unknown joint '%s'", name);
+}
+
+// ------------------------------------------------------------------ batch
+struct GraphKey { int nsub, goal_body; float geofence; bool operator<(const GraphKey &o) const { return std::tie(nsub, goal_body, geofence) < std::tie(o.nsub, o.goal_body, o.geofence); } };
+
+struct hsr_batch {
+    const hsr_model *model = nullptr;
+    int N = 0, device = 0;
+    hipStream_t stream = nullptr;
+    DevModel dm{};
+    DevState ds{};
+    std::vector<void *> allocs;
+    float *d_stage = nullptr;      // staging for host-pointer API: max(N*(nq+nv), ...) floats
+    size_t stage_floats = 0;
+    uint8_t *d_stage_u8 = nullptr;
+    int32_t *d_stage_i32 = nullptr;
+    int hot_threads = 64;
+    size_t hot_lds_bytes = 0;
+    bool use_graph = true, profiling = false;
+    std::map<GraphKey, hipGraphExec_t> graphs;
+    float last_total_ms = 0, last_kernel_ms[3] = {0, 0, 0};
+    int last_launches[3] = {0, 0, 0};
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::vector<hipEvent_t> kev;
+};
+
+template <typename T>
+static int dalloc(hsr_batch *b, T **p, size_t count) {
+    void *q = nullptr;
+    HIPCHK(hipMalloc(&q, (count ? count : 1) * sizeof(T)));
+    HIPCHK(hipMemset(q, 0, (count ? count : 1) * sizeof(T)));
+    b->allocs.push_back(q);
+    *p = (T *)q;
+    return HSR_OK;
+}
+static int upload_f(hsr_batch *b, const float **dst, const hsr_model *m, const char *name) {
+    size_t cnt = 0;
+    const double *src = m->f64(name, &cnt);
+    if (!src) return fail(HSR_EBLOB, "blob entry '%s' missing", name);
+    std::vector<float> tmp(cnt ? cnt : 1, 0.f);
+    for (size_t i = 0; i < cnt; i++) tmp[i] = (float)src[i];
+    float *d;
+    int rc = dalloc(b, &d, tmp.size());
+    if (rc) return rc;
+    HIPCHK(hipMemcpy(d, tmp.data(), tmp.size() * sizeof(float), hipMemcpyHostToDevice));
+    *dst = d;
+    return HSR_OK;
+}
+static int upload_i(hsr_batch *b, const int **dst, const hsr_model *m, const char *name) {
+    size_t cnt = 0;
+    const int *src = m->i32(name, &cnt);
+    if (!src) return fail(HSR_EBLOB, "blob entry '%s' missing", name);
+    int *d;
+    int rc = dalloc(b, &d, cnt ? cnt : 1);
+    if (rc) return rc;
+    if (cnt) HIPCHK(hipMemcpy(d, src, cnt * sizeof(int), hipMemcpyHostToDevice));
+    *dst = d;
+    return HSR_OK;
+}
+
+static void quat2mat_h(const double *q, float *mt) {
+    double n = sqrt(q[0]*q[0] + q[1]*q[1] + q[2]*q[2] + q[3]*q[3]);
+    double w = q[0]/n, x = q[1]/n, y = q[2]/n, z = q[3]/n;
+    mt[0] = (float)(1 - 2*(y*y + z*z)); mt[1] = (float)(2*(x*y - w*z)); mt[2] = (float)(2*(x*z + w*y));
+    mt[3] = (float)(2*(x*y + w*z)); mt[4] = (float)(1 - 2*(x*x + z*z)); mt[5] = (float)(2*(y*z - w*x));
+    mt[6] = (float)(2*(x*z - w*y)); mt[7] = (float)(2*(y*z + w*x)); mt[8] = (float)(1 - 2*(x*x + y*y));
+}
+static int upload_mats(hsr_batch *b, const float **dst, const hsr_model *m, const char *quat_name) {
+    size_t cnt = 0;
+    const double *q = m->f64(quat_name, &cnt);
+    if (!q) return fail(HSR_EBLOB, "blob entry '%s' missing", quat_name);
+    size_t n = cnt / 4;
+    std::vector<float> tmp(n * 9 + 1);
+    for (size_t i = 0; i < n; i++) quat2mat_h(q + 4 * i, tmp.data() + 9 * i);
+    float *d;
+    int rc = dalloc(b, &d, tmp.size());
+    if (rc) return rc;
+    HIPCHK(hipMemcpy(d, tmp.data(), tmp.size() * sizeof(float), hipMemcpyHostToDevice));
+    *dst = d;
+    return HSR_OK;
+}
+
+// ------------------------------------------------------------------ small layout / IO kernels
+__global__ void k_aos_to_soa(float *dst, const float *src, int rows, int N) {   // src [N,rows] -> dst [rows][N]
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)rows * N) return;
+    int r = (int)(i / N), e = (int)(i % N);
+    dst[i] = src[(size_t)e * rows + r];
+}
+__global__ void k_soa_to_aos(float *dst, const float *src, int rows, int N, int dst_stride, int dst_off) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)rows * N) return;
+    int r = (int)(i / N), e = (int)(i % N);
+    dst[(size_t)e * dst_stride + dst_off + r] = src[i];
+}
+__global__ void k_begin_step(DevState s, const float *ctrl_in, int nu) {
+    int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= s.N) return;
+    for (int a = 0; a < nu; a++) s.ctrl[(size_t)a * s.N + e] = ctrl_in[(size_t)e * nu + a];
+    s.done[e] = 0;
+    s.nsteps[e] = 0;
+}
+__global__ void k_end_step(DevState s, float *reward, uint8_t *done, int32_t *nsteps) {
+    int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= s.N) return;
+    if (reward) reward[e] = s.done[e] ? 1.f : 0.f;
+    if (done) done[e] = (uint8_t)(s.done[e] != 0);
+    if (nsteps) nsteps[e] = s.nsteps[e];
+}
+__global__ void k_clear_done(DevState s) {
+    int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < s.N) s.done[e] = 0;
+}
+__global__ void k_reset(DevModel m, DevState s, const uint8_t *mask, const float *qpos0_env, const float *qpos0_model, const float *mocap) {
+    int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= s.N) return;
+    s.done[e] = 0;
+    if (mask && !mask[e]) return;
+    const int N = s.N;
+    for (int i = 0; i < m.nq; i++) s.qpos[(size_t)i * N + e] = qpos0_env ? qpos0_env[(size_t)e * m.nq + i] : qpos0_model[i];
+    for (int i = 0; i < m.nv; i++) { s.qvel[(size_t)i * N + e] = 0; s.warm[(size_t)i * N + e] = 0; s.qacc[(size_t)i * N + e] = 0; }
+    for (int i = 0; i < m.nu; i++) s.ctrl[(size_t)i * N + e] = 0;
+    for (int k = 0; k < 3; k++) s.mocap[(size_t)k * N + e] = mocap ? mocap[(size_t)e * 3 + k] : 0.f;
+    s.time[e] = 0; s.bad[e] = 0; s.nsteps[e] = 0;
+}
+__global__ void k_body_xpos(DevModel m, DevState s, int body, float *out) {
+    int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= s.N) return;
+    const int N = s.N;
+    v3 p;
+    if (m.body_mocap[body]) p = mk3(s.mocap[e], s.mocap[N + e], s.mocap[2 * N + e]);
+    else {
+        const int l = m.body_link[body];
+        View xpos{s.xpos + e, N}, xmat{s.xmat + e, N};
+        p = xpos.get3(l) + mulmv(xmat.getm(l), ld3(m.body_pos, body));
+    }
+    out[3 * e] = p.x; out[3 * e + 1] = p.y; out[3 * e + 2] = p.z;
+}
+__global__ void k_i32_to_f32(float *dst, const int *src, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = (float)src[i];
+}
+__global__ void k_contacts_out(DevModel m, DevState s, float *out) {   // [N, nslot, 7]; empty slot: dist = +1
+    int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= s.N) return;
+    const int N = s.N;
+    for (int p = 0; p < m.npair; p++) {
+        const int cnt = s.ncon_pair[(size_t)p * N + e];
+        for (int slot = m.pair_slot[p]; slot < m.pair_slot[p + 1]; slot++) {
+            float *o = out + ((size_t)e * m.nslot + slot) * 7;
+            const bool used = slot - m.pair_slot[p] < cnt;
+            for (int k = 0; k < 7; k++) o[k] = used ? s.con[(size_t)(slot * 7 + k) * N + e] : (k == 6 ? 1.f : 0.f);
+        }
+    }
+}
+__global__ void k_expand_M(DevState s, float *out, int nv) {   // packed [nM][N] -> [N,nv,nv]
+    int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= s.N) return;
+    for (int i = 0; i < nv; i++) for (int j = 0; j <= i; j++) {
+        const float v = s.M[(size_t)(i * (i + 1) / 2 + j) * s.N + e];
+        out[((size_t)e * nv + i) * nv + j] = v; out[((size_t)e * nv + j) * nv + i] = v;
+    }
+}
+
+static inline dim3 grid1(size_t n, int t = 256) { return dim3((unsigned)((n + t - 1) / t)); }
+
+extern "C" int hsr_batch_create(const hsr_model *m, int n_envs, int device_id, hsr_batch **out) {
+    if (!m || !out || n_envs <= 0) return fail(HSR_EINVAL, "bad arguments to hsr_batch_create");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(HSR_EDEVICE, "no HIP device available%s");
+    if (device_id < 0 || device_id >= ndev) return fail(HSR_EINVAL, "device id out of range");
+    HIPCHK(hipSetDevice(device_id));
+    hsr_batch *b = new hsr_batch();
+    b->model = m; b->N = n_envs; b->device = device_id;
+    HIPCHK(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
+    DevModel &d = b->dm;
+    const int *sz = m->sizes;
+    d.nq = sz[HSR_NQ]; d.nv = sz[HSR_NV]; d.nu = sz[HSR_NU]; d.nlink = sz[HSR_NLINK]; d.nbody = sz[HSR_NBODY];
+    d.ngeom = sz[HSR_NGEOM]; d.npair = sz[HSR_NPAIR]; d.nslot = sz[HSR_NSLOT]; d.nconmax = sz[HSR_NCONMAX]; d.njmax = sz[HSR_NJMAX];
+    d.nM = d.nv * (d.nv + 1) / 2;
+    d.timestep = (float)m->opt[0]; d.impratio = (float)m->opt[1]; d.gravz = (float)m->opt[2]; d.tolerance = (float)m->opt[3];
+    d.iterations = (int)m->opt[4]; d.ls_iterations = (int)m->opt[5]; d.ls_tolerance = (float)m->opt[6];
+    d.mpr_tolerance = (float)m->opt[7]; d.mpr_iterations = (int)m->opt[8]; d.meaninertia = (float)m->opt[9];
+    int rc = 0;
+#define UI(f) if ((rc = upload_i(b, &d.f, m, #f))) { return rc; }
+#define UF(f) if ((rc = upload_f(b, &d.f, m, #f))) { return rc; }
+    UI(link_parent) UI(link_dofadr) UI(link_dofnum) UI(link_qposadr) UI(link_free)
+    UF(link_pos) UF(link_mass) UF(link_com) UF(link_inertia)
+    UI(dof_link) UI(dof_type) UI(dof_parent) UI(dof_qposadr) UI(dof_limited)
+    UF(dof_axis) UF(dof_pos) UF(dof_damping) UF(dof_invweight0) UF(dof_range) UF(dof_solref) UF(dof_solimp)
+    UI(body_link) UI(body_mocap) UF(body_pos)
+    UI(geom_type) UI(geom_link) UI(geom_meshadr) UI(geom_meshnum)
+    UF(geom_pos) UF(geom_size) UF(geom_rbound) UF(geom_invweight) UF(mesh_vert)
+    UI(pair_geom1) UI(pair_geom2) UI(pair_fn) UI(pair_condim) UI(pair_slot)
+    UF(pair_friction) UF(pair_solref) UF(pair_solimp)
+    UI(act_dof) UF(act_gear) UF(act_kp) UF(act_ctrlrange) UF(act_forcerange)
+#undef UI
+#undef UF
+    if ((rc = upload_mats(b, &d.link_mat, m, "link_quat"))) return rc;
+    if ((rc = upload_mats(b, &d.geom_mat, m, "geom_quat"))) return rc;
+    d.any_damping = 0;
+    { size_t cnt; const double *dmp = m->f64("dof_damping", &cnt); for (size_t i = 0; i < cnt; i++) if (dmp[i] > 0) d.any_damping = 1; }
+
+    DevState &s = b->ds;
+    const size_t N = (size_t)n_envs;
+    s.N = n_envs;
+#define DA(field, rows) if ((rc = dalloc(b, &s.field, (size_t)(rows) * N))) return rc;
+    DA(qpos, d.nq) DA(qvel, d.nv) DA(ctrl, d.nu) DA(mocap, 3) DA(warm, d.nv) DA(time, 1)
+    DA(done, 1) DA(bad, 1) DA(nsteps, 1)
+    DA(xpos, 3 * d.nlink) DA(xmat, 9 * d.nlink) DA(dof_ang, 3 * d.nv) DA(dof_lin, 3 * d.nv) DA(dof_anchor, 3 * d.nv)
+    DA(con, 7 * d.nslot) DA(ncon_pair, d.npair)
+    DA(M, d.nM) DA(qacc, d.nv) DA(qacc_smooth, d.nv) DA(qfrc_smooth, d.nv) DA(qfrc_constraint, d.nv)
+    DA(ncon, 1) DA(nefc, 1) DA(niter, 1)
+    // solver workspace rows
+    int o = 0;
+    s.o_lw = o; o += 3 * d.nlink; s.o_lvo = o; o += 3 * d.nlink; s.o_lal = o; o += 3 * d.nlink; s.o_lao = o; o += 3 * d.nlink;
+    s.o_J = o; o += d.njmax * d.nv;
+    s.o_D = o; o += d.njmax; s.o_aref = o; o += d.njmax; s.o_jar = o; o += d.njmax; s.o_jv = o; o += d.njmax; s.o_gr = o; o += d.njmax;
+    s.o_cpair = o; o += d.nconmax; s.o_cmu = o; o += d.nconmax;
+    s.o_T = o; o += 6 * d.nv;
+    s.hot_floats = 2 * d.nM + 8 * d.nv;
+    s.o_hot = o; o += s.hot_floats;
+    s.ws_floats = o;
+    DA(ws, o)
+#undef DA
+    b->hot_threads = 64;
+    b->hot_lds_bytes = (size_t)s.hot_floats * 64 * sizeof(float);
+    s.hot_in_lds = b->hot_lds_bytes <= 150 * 1024 ? 1 : 0;
+    if (!s.hot_in_lds) b->hot_lds_bytes = 0;
+    else if (b->hot_lds_bytes > 64 * 1024)
+        HIPCHK(hipFuncSetAttribute((const void *)k_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->hot_lds_bytes));
+    b->stage_floats = N * (size_t)(std::max(std::max(d.nq + d.nv, 7 * d.nslot), std::max(d.nv * d.nv, 9 * d.nlink)) + d.nu + d.nq + d.nv + 4) + 16;
+    if ((rc = dalloc(b, &b->d_stage, b->stage_floats))) return rc;
+    if ((rc = dalloc(b, &b->d_stage_u8, N))) return rc;
+    if ((rc = dalloc(b, &b->d_stage_i32, N))) return rc;
+    HIPCHK(hipEventCreate(&b->ev0));
+    HIPCHK(hipEventCreate(&b->ev1));
+    // initial state = mj_resetData
+    float *d_q0;
+    if ((rc = dalloc(b, &d_q0, (size_t)d.nq))) return rc;
+    HIPCHK(hipMemcpy(d_q0, m->qpos0.data(), d.nq * sizeof(float), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_reset, grid1(N), dim3(256), 0, b->stream, b->dm, b->ds, (const uint8_t *)nullptr, (const float *)nullptr, (const float *)d_q0, (const float *)nullptr);
+    HIPCHK(hipStreamSynchronize(b->stream));
+    *out = b;
+    return HSR_OK;
+}
+
+extern "C" void hsr_batch_destroy(hsr_batch *b) {
+    if (!b) return;
+    hipSetDevice(b->device);
+    hipStreamSynchronize(b->stream);
+    for (auto &kv : b->graphs) hipGraphExecDestroy(kv.second);
+    for (void *p : b->allocs) hipFree(p);
+    for (hipEvent_t ev : b->kev) hipEventDestroy(ev);
+    if (b->ev0) hipEventDestroy(b->ev0);
+    if (b->ev1) hipEventDestroy(b->ev1);
+    hipStreamDestroy(b->stream);
+    delete b;
+}
+extern "C" int hsr_batch_size(const hsr_batch *b) { return b->N; }
+extern "C" void *hsr_batch_stream(const hsr_batch *b) { return (void *)b->stream; }
+extern "C" int hsr_batch_sync(hsr_batch *b) { HIPCHK(hipSetDevice(b->device)); HIPCHK(hipStreamSynchronize(b->stream)); return HSR_OK; }
+extern "C" int hsr_batch_set_profiling(hsr_batch *b, int on) { b->profiling = on != 0; return HSR_OK; }
+extern "C" int hsr_batch_set_graph(hsr_batch *b, int on) { b->use_graph = on != 0; return HSR_OK; }
+
+// one substep = 3 launches on the batch stream
+static void launch_substep(hsr_batch *b, int mode, int goal_body, float geofence, int debug, hipStream_t st, bool timed) {
+    const int N = b->N;
+    auto rec = [&](void) { if (timed) { hipEvent_t ev; hipEventCreate(&ev); hipEventRecord(ev, st); b->kev.push_back(ev); } };
+    rec();
+    hipLaunchKernelGGL(k_kinematics, dim3((N + 63) / 64), dim3(64), 0, st, b->dm, b->ds);
+    rec();
+    if (b->dm.npair > 0) hipLaunchKernelGGL(k_collide, dim3((N + 63) / 64, b->dm.npair), dim3(64), 0, st, b->dm, b->ds);
+    rec();
+    hipLaunchKernelGGL(k_solve, dim3((N + 63) / 64), dim3(64), b->hot_lds_bytes, st, b->dm, b->ds, mode, goal_body, geofence, debug);
+    rec();
+}
+
+extern "C" int hsr_batch_forward(hsr_batch *b) {
+    HIPCHK(hipSetDevice(b->device));
+    hipLaunchKernelGGL(k_clear_done, grid1(b->N), dim3(256), 0, b->stream, b->ds);
+    launch_substep(b, 0, -1, 0.f, 1, b->stream, false);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(b->stream));
+    return HSR_OK;
+}
+
+extern "C" int hsr_batch_reset(hsr_batch *b, const uint8_t *mask, const float *qpos0, const float *mocap) {
+    HIPCHK(hipSetDevice(b->device));
+    const size_t N = b->N;
+    const int nq = b->dm.nq;
+    float *d_q = nullptr, *d_m = nullptr, *d_q0m = b->d_stage;
+    size_t off = (size_t)nq;
+    HIPCHK(hipMemcpyAsync(d_q0m, b->model->qpos0.data(), nq * sizeof(float), hipMemcpyHostToDevice, b->stream));
+    if (qpos0) { d_q = b->d_stage + off; off += N * nq; HIPCHK(hipMemcpyAsync(d_q, qpos0, N * nq * sizeof(float), hipMemcpyHostToDevice, b->stream)); }
+    if (mocap) { d_m = b->d_stage + off; off += N * 3; HIPCHK(hipMemcpyAsync(d_m, mocap, N * 3 * sizeof(float), hipMemcpyHostToDevice, b->stream)); }
+    if (off > b->stage_floats) return fail(HSR_EINVAL, "staging overflow in reset");
+    if (mask) HIPCHK(hipMemcpyAsync(b->d_stage_u8, mask, N, hipMemcpyHostToDevice, b->stream));
+    hipLaunchKernelGGL(k_reset, grid1(N), dim3(256), 0, b->stream, b->dm, b->ds, mask ? (const uint8_t *)b->d_stage_u8 : (const uint8_t *)nullptr,
+                       (const float *)d_q, (const float *)d_q0m, (const float *)d_m);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(b->stream));
+    return hsr_batch_forward(b);
+}
+
+static int to_device_soa(hsr_batch *b, float *dst, const float *host, int rows) {
+    const size_t n = (size_t)rows * b->N;
+    if (n > b->stage_floats) return fail(HSR_EINVAL, "staging overflow");
+    HIPCHK(hipMemcpyAsync(b->d_stage, host, n * sizeof(float), hipMemcpyHostToDevice, b->stream));
+    hipLaunchKernelGGL(k_aos_to_soa, grid1(n), dim3(256), 0, b->stream, dst, (const float *)b->d_stage, rows, b->N);
+    HIPCHK(hipStreamSynchronize(b->stream));
+    return HSR_OK;
+}
+static int to_host_aos(hsr_batch *b, float *host, const float *src, int rows) {
+    const size_t n = (size_t)rows * b->N;
+    if (n > b->stage_floats) return fail(HSR_EINVAL, "staging overflow");
+    hipLaunchKernelGGL(k_soa_to_aos, grid1(n), dim3(256), 0, b->stream, b->d_stage, src, rows, b->N, rows, 0);
+    HIPCHK(hipMemcpyAsync(host, b->d_stage, n * sizeof(float), hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    return HSR_OK;
+}
+
+extern "C" int hsr_batch_get_state(hsr_batch *b, float *time, float *qpos, float *qvel) {
+    HIPCHK(hipSetDevice(b->device));
+    int rc;
+    if (time && (rc = to_host_aos(b, time, b->ds.time, 1))) return rc;
+    if (qpos && (rc = to_host_aos(b, qpos, b->ds.qpos, b->dm.nq))) return rc;
+    if (qvel && (rc = to_host_aos(b, qvel, b->ds.qvel, b->dm.nv))) return rc;
+    return HSR_OK;
+}
+extern "C" int hsr_batch_set_state(hsr_batch *b, const float *time, const float *qpos, const float *qvel) {
+    HIPCHK(hipSetDevice(b->device));
+    int rc;
+    if (time && (rc = to_device_soa(b, b->ds.time, time, 1))) return rc;
+    if (qpos && (rc = to_device_soa(b, b->ds.qpos, qpos, b->dm.nq))) return rc;
+    if (qvel && (rc = to_device_soa(b, b->ds.qvel, qvel, b->dm.nv))) return rc;
+    return hsr_batch_forward(b);
+}
+extern "C" int hsr_batch_set_mocap(hsr_batch *b, const float *mocap) { HIPCHK(hipSetDevice(b->device)); return to_device_soa(b, b->ds.mocap, mocap, 3); }
+extern "C" int hsr_batch_set_warmstart(hsr_batch *b, const float *w) { HIPCHK(hipSetDevice(b->device)); return to_device_soa(b, b->ds.warm, w, b->dm.nv); }
+extern "C" int hsr_batch_get_warmstart(hsr_batch *b, float *w) { HIPCHK(hipSetDevice(b->device)); return to_host_aos(b, w, b->ds.warm, b->dm.nv); }
+
+extern "C" int hsr_batch_step_dev(hsr_batch *b, const float *d_ctrl, int n_substeps, int goal_body, float geofence,
+                                  float *d_obs, float *d_reward, uint8_t *d_done, int32_t *d_nsteps) {
+    if (!b || !d_ctrl || n_substeps < 0) return fail(HSR_EINVAL, "bad arguments to hsr_batch_step");
+    if (goal_body >= b->dm.nbody) return fail(HSR_EINVAL, "goal body out of range");
+    HIPCHK(hipSetDevice(b->device));
+    const int N = b->N;
+    hipStream_t st = b->stream;
+    if (b->profiling) {
+        for (hipEvent_t ev : b->kev) hipEventDestroy(ev);
+        b->kev.clear();
+        HIPCHK(hipEventRecord(b->ev0, st));
+    }
+    hipLaunchKernelGGL(k_begin_step, grid1(N), dim3(256), 0, st, b->ds, d_ctrl, b->dm.nu);
+    if (b->use_graph && !b->profiling && n_substeps > 0) {
+        GraphKey key{n_substeps, goal_body, geofence};
+        auto it = b->graphs.find(key);
+        if (it == b->graphs.end()) {
+            hipGraph_t graph;
+            HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+            for (int i = 0; i < n_substeps; i++) launch_substep(b, 1, goal_body, geofence, 0, st, false);
+            HIPCHK(hipStreamEndCapture(st, &graph));
+            hipGraphExec_t exec;
+            HIPCHK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+            hipGraphDestroy(graph);
+            if (b->graphs.size() >= 8) { for (auto &kv : b->graphs) hipGraphExecDestroy(kv.second); b->graphs.clear(); }
+            it = b->graphs.emplace(key, exec).first;
+        }
+        HIPCHK(hipGraphLaunch(it->second, st));
+    } else {
+        for (int i = 0; i < n_substeps; i++) launch_substep(b, 1, goal_body, geofence, 0, st, b->profiling);
+    }
+    if (d_obs) {
+        const int nq = b->dm.nq, nv = b->dm.nv;
+        hipLaunchKernelGGL(k_soa_to_aos, grid1((size_t)nq * N), dim3(256), 0, st, d_obs, (const float *)b->ds.qpos, nq, N, nq + nv, 0);
+        hipLaunchKernelGGL(k_soa_to_aos, grid1((size_t)nv * N), dim3(256), 0, st, d_obs, (const float *)b->ds.qvel, nv, N, nq + nv, nq);
+    }
+    hipLaunchKernelGGL(k_end_step, grid1(N), dim3(256), 0, st, b->ds, d_reward, d_done, d_nsteps);
+    HIPCHK(hipGetLastError());
+    if (b->profiling) {
+        HIPCHK(hipEventRecord(b->ev1, st));
+        HIPCHK(hipEventSynchronize(b->ev1));
+        HIPCHK(hipEventElapsedTime(&b->last_total_ms, b->ev0, b->ev1));
+        for (int k = 0; k < 3; k++) { b->last_kernel_ms[k] = 0; b->last_launches[k] = 0; }
+        for (size_t i = 0; i + 3 < b->kev.size(); i += 4)
+            for (int k = 0; k < 3; k++) { float ms = 0; hipEventElapsedTime(&ms, b->kev[i + k], b->kev[i + k + 1]); b->last_kernel_ms[k] += ms; b->last_launches[k]++; }
+    }
+    return HSR_OK;
+}
+
+extern "C" int hsr_batch_step(hsr_batch *b, const float *ctrl, int n_substeps, int goal_body, float geofence,
+                              float *obs, float *reward, uint8_t *done, int32_t *nsteps) {
+    if (!b || !ctrl) return fail(HSR_EINVAL, "bad arguments to hsr_batch_step");
+    HIPCHK(hipSetDevice(b->device));
+    const size_t N = b->N;
+    const int nu = b->dm.nu, no = b->dm.nq + b->dm.nv;
+    // staging layout: [ctrl N*nu | obs N*no | reward N]
+    if (N * (size_t)(nu + no + 1) > b->stage_floats) return fail(HSR_EINVAL, "staging overflow in step");
+    float *d_ctrl = b->d_stage, *d_obs = b->d_stage + N * nu, *d_rew = d_obs + N * no;
+    HIPCHK(hipMemcpyAsync(d_ctrl, ctrl, N * nu * sizeof(float), hipMemcpyHostToDevice, b->stream));
+    int rc = hsr_batch_step_dev(b, d_ctrl, n_substeps, goal_body, geofence, obs ? d_obs : nullptr, reward ? d_rew : nullptr,
+                                done ? b->d_stage_u8 : nullptr, nsteps ? b->d_stage_i32 : nullptr);
+    if (rc) return rc;
+    if (obs) HIPCHK(hipMemcpyAsync(obs, d_obs, N * no * sizeof(float), hipMemcpyDeviceToHost, b->stream));
+    if (reward) HIPCHK(hipMemcpyAsync(reward, d_rew, N * sizeof(float), hipMemcpyDeviceToHost, b->stream));
+    if (done) HIPCHK(hipMemcpyAsync(done, b->d_stage_u8, N, hipMemcpyDeviceToHost, b->stream));
+    if (nsteps) HIPCHK(hipMemcpyAsync(nsteps, b->d_stage_i32, N * sizeof(int32_t), hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    return HSR_OK;
+}
+
+extern "C" int hsr_batch_body_xpos(hsr_batch *b, int body_id, float *out) {
+    if (body_id < 0 || body_id >= b->dm.nbody) return fail(HSR_EINVAL, "body id out of range");
+    HIPCHK(hipSetDevice(b->device));
+    hipLaunchKernelGGL(k_body_xpos, grid1(b->N), dim3(256), 0, b->stream, b->dm, b->ds, body_id, b->d_stage);
+    HIPCHK(hipMemcpyAsync(out, b->d_stage, (size_t)b->N * 3 * sizeof(float), hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    return HSR_OK;
+}
+
+extern "C" int hsr_batch_bad_state(hsr_batch *b, uint8_t *out) {
+    HIPCHK(hipSetDevice(b->device));
+    std::vector<int> tmp(b->N);
+    HIPCHK(hipMemcpyAsync(tmp.data(), b->ds.bad, (size_t)b->N * sizeof(int), hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    int any = 0;
+    for (int i = 0; i < b->N; i++) { out[i] = (uint8_t)(tmp[i] != 0); any |= tmp[i]; }
+    return any ? HSR_EBADSTATE : HSR_OK;
+}
+
+extern "C" int hsr_batch_get_field(hsr_batch *b, int field, float *out) {
+    HIPCHK(hipSetDevice(b->device));
+    const DevModel &d = b->dm;
+    const size_t N = b->N;
+    switch (field) {
+    case HSR_F_XPOS: return to_host_aos(b, out, b->ds.xpos, 3 * d.nlink);
+    case HSR_F_XMAT: return to_host_aos(b, out, b->ds.xmat, 9 * d.nlink);
+    case HSR_F_QACC: return to_host_aos(b, out, b->ds.qacc, d.nv);
+    case HSR_F_QACC_SMOOTH: return to_host_aos(b, out, b->ds.qacc_smooth, d.nv);
+    case HSR_F_QFRC_SMOOTH: return to_host_aos(b, out, b->ds.qfrc_smooth, d.nv);
+    case HSR_F_QFRC_CONSTRAINT: return to_host_aos(b, out, b->ds.qfrc_constraint, d.nv);
+    case HSR_F_M:
+        hipLaunchKernelGGL(k_expand_M, grid1(N), dim3(256), 0, b->stream, b->ds, b->d_stage, d.nv);
+        HIPCHK(hipMemcpyAsync(out, b->d_stage, N * d.nv * d.nv * sizeof(float), hipMemcpyDeviceToHost, b->stream));
+        HIPCHK(hipStreamSynchronize(b->stream));
+        return HSR_OK;
+    case HSR_F_NCON: case HSR_F_NEFC: case HSR_F_NITER: {
+        const int *src = field == HSR_F_NCON ? b->ds.ncon : (field == HSR_F_NEFC ? b->ds.nefc : b->ds.niter);
+        hipLaunchKernelGGL(k_i32_to_f32, grid1(N), dim3(256), 0, b->stream, b->d_stage, src, N);
+        HIPCHK(hipMemcpyAsync(out, b->d_stage, N * sizeof(float), hipMemcpyDeviceToHost, b->stream));
+        HIPCHK(hipStreamSynchronize(b->stream));
+        return HSR_OK; }
+    case HSR_F_CONTACT:
+        hipLaunchKernelGGL(k_contacts_out, grid1(N), dim3(256), 0, b->stream, b->dm, b->ds, b->d_stage);
+        HIPCHK(hipMemcpyAsync(out, b->d_stage, N * d.nslot * 7 * sizeof(float), hipMemcpyDeviceToHost, b->stream));
+        HIPCHK(hipStreamSynchronize(b->stream));
+        return HSR_OK;
+    default: return fail(HSR_EINVAL, "unknown field");
+    }
+}
+
+extern "C" int hsr_batch_last_timing(hsr_batch *b, float *total_ms, float *kernel_ms, int *launches) {
+    if (total_ms) *total_ms = b->last_total_ms;
+    for (int k = 0; k < 3; k++) { if (kernel_ms) kernel_ms[k] = b->last_kernel_ms[k]; if (launches) launches[k] = b->last_launches[k]; }
+    return HSR_OK;
+}

@@ -1,0 +1,49 @@
+// Device-side model tables and per-batch state (struct-of-arrays, [field][env]).
+#pragma once
+#include <stdint.h>
+
+enum { DOF_SLIDE = 0, DOF_HINGE = 1, DOF_FREE_LIN = 2, DOF_FREE_ANG = 3 };
+enum { GEOM_PLANE = 0, GEOM_SPHERE = 2, GEOM_CYLINDER = 5, GEOM_BOX = 6, GEOM_MESH = 7 };
+enum { FN_PLANE_BOX = 0, FN_PLANE_CONVEX = 1, FN_BOX_BOX = 2, FN_CONVEX = 3 };
+
+// constant tables (device pointers; fp64 blob values converted to fp32 once at load)
+struct DevModel {
+    int nq, nv, nu, nlink, nbody, ngeom, npair, nslot, nconmax, njmax, nM;
+    float timestep, impratio, gravz, tolerance, ls_tolerance, mpr_tolerance, meaninertia;
+    int iterations, ls_iterations, mpr_iterations, any_damping;
+    const int *link_parent, *link_dofadr, *link_dofnum, *link_qposadr, *link_free;
+    const float *link_pos, *link_mat, *link_mass, *link_com, *link_inertia;
+    const int *dof_link, *dof_type, *dof_parent, *dof_qposadr, *dof_limited;
+    const float *dof_axis, *dof_pos, *dof_damping, *dof_invweight0, *dof_range, *dof_solref, *dof_solimp;
+    const int *body_link, *body_mocap;
+    const float *body_pos;
+    const int *geom_type, *geom_link, *geom_meshadr, *geom_meshnum;
+    const float *geom_pos, *geom_mat, *geom_size, *geom_rbound, *geom_invweight, *mesh_vert;
+    const int *pair_geom1, *pair_geom2, *pair_fn, *pair_condim, *pair_slot;
+    const float *pair_friction, *pair_solref, *pair_solimp;
+    const int *act_dof;
+    const float *act_gear, *act_kp, *act_ctrlrange, *act_forcerange;
+};
+
+// per-batch buffers; every array is [rows][N] with the env index fastest (coalesced across lanes)
+struct DevState {
+    int N;
+    // persistent simulation state
+    float *qpos, *qvel, *ctrl, *mocap, *warm, *time;
+    int *done, *bad, *nsteps;
+    // kinematics outputs
+    float *xpos, *xmat, *dof_ang, *dof_lin, *dof_anchor;
+    // collision outputs: contact slots (7 floats: pos, normal, dist) and per-pair counts
+    float *con;
+    int *ncon_pair;
+    // dynamics / solver outputs kept for introspection
+    float *M, *qacc, *qacc_smooth, *qfrc_smooth, *qfrc_constraint;
+    int *ncon, *nefc, *niter;
+    // solver workspace: [ws_floats][N]
+    float *ws;
+    int ws_floats;
+    // offsets (in rows) into ws
+    int o_lw, o_lvo, o_lal, o_lao, o_J, o_D, o_aref, o_jar, o_jv, o_gr, o_cpair, o_cmu, o_T, o_hot;
+    int hot_floats;      // rows of the "hot" per-thread block (M, H, vectors); lives in LDS when it fits
+    int hot_in_lds;
+};

@@ -1,0 +1,218 @@
+"""ctypes binding of libhsrsim.so (include/hsrsim.h) - the batched, GPU-resident stand-in for the
+slice of ``mujoco_py`` the reference touches (hsr/mujoco_env.py:33-34,84,87-94,101-103;
+hsr/env.py:116,123,144,153,169,175-176,180,184,209).
+
+There is no CPU fallback: if the shared library is missing or no GPU is visible, construction
+raises (``DependencyNotInstalled`` mirrors hsr/mujoco_env.py:12-15).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+import numpy as np
+
+from .compiler import Model
+
+_HERE = Path(__file__).parent
+LIB_PATH = _HERE / "libhsrsim.so"
+
+
+class DependencyNotInstalled(ImportError):
+    """Raised when libhsrsim.so (or a GPU) is unavailable - reference: gym.error.DependencyNotInstalled
+    raised by hsr/mujoco_env.py:12-15 when mujoco_py is missing."""
+
+
+class MujocoException(RuntimeError):
+    """Some env reached a non-finite state (reference: mujoco_py.MujocoException on MuJoCo warnings)."""
+
+
+EXPORTS = [
+    "hsr_last_error", "hsr_model_load", "hsr_model_destroy", "hsr_model_size", "hsr_model_timestep",
+    "hsr_model_ctrlrange", "hsr_model_qpos0", "hsr_model_body_id", "hsr_model_joint_qpos_addr",
+    "hsr_batch_create", "hsr_batch_destroy", "hsr_batch_size", "hsr_batch_stream", "hsr_batch_sync",
+    "hsr_batch_reset", "hsr_batch_get_state", "hsr_batch_set_state", "hsr_batch_set_mocap",
+    "hsr_batch_set_warmstart", "hsr_batch_get_warmstart", "hsr_batch_forward", "hsr_batch_step",
+    "hsr_batch_step_dev", "hsr_batch_body_xpos", "hsr_batch_bad_state", "hsr_batch_get_field",
+    "hsr_batch_set_profiling", "hsr_batch_last_timing", "hsr_batch_set_graph",
+]
+
+F_XPOS, F_XMAT, F_M, F_QACC, F_QACC_SMOOTH, F_QFRC_SMOOTH, F_QFRC_CONSTRAINT, F_NCON, F_NEFC, F_CONTACT, F_NITER = range(11)
+
+_lib = None
+
+
+def load_library():
+    """dlopen libhsrsim.so and declare prototypes; raises DependencyNotInstalled if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise DependencyNotInstalled(
+            f"{LIB_PATH} not built. Run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950); there is no CPU fallback for the product path.")
+    L = C.CDLL(str(LIB_PATH))
+    vp, fp, u8p, i32p = C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_uint8), C.POINTER(C.c_int32)
+    L.hsr_last_error.restype = C.c_char_p
+    L.hsr_model_load.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(vp)]
+    L.hsr_model_destroy.argtypes = [vp]; L.hsr_model_destroy.restype = None
+    L.hsr_model_size.argtypes = [vp, C.c_int]
+    L.hsr_model_timestep.argtypes = [vp]; L.hsr_model_timestep.restype = C.c_double
+    L.hsr_model_ctrlrange.argtypes = [vp, fp]
+    L.hsr_model_qpos0.argtypes = [vp, fp]
+    L.hsr_model_body_id.argtypes = [vp, C.c_char_p]
+    L.hsr_model_joint_qpos_addr.argtypes = [vp, C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.hsr_batch_create.argtypes = [vp, C.c_int, C.c_int, C.POINTER(vp)]
+    L.hsr_batch_destroy.argtypes = [vp]; L.hsr_batch_destroy.restype = None
+    L.hsr_batch_size.argtypes = [vp]
+    L.hsr_batch_stream.argtypes = [vp]; L.hsr_batch_stream.restype = vp
+    L.hsr_batch_sync.argtypes = [vp]
+    L.hsr_batch_reset.argtypes = [vp, u8p, fp, fp]
+    L.hsr_batch_get_state.argtypes = [vp, fp, fp, fp]
+    L.hsr_batch_set_state.argtypes = [vp, fp, fp, fp]
+    L.hsr_batch_set_mocap.argtypes = [vp, fp]
+    L.hsr_batch_set_warmstart.argtypes = [vp, fp]
+    L.hsr_batch_get_warmstart.argtypes = [vp, fp]
+    L.hsr_batch_forward.argtypes = [vp]
+    L.hsr_batch_step.argtypes = [vp, fp, C.c_int, C.c_int, C.c_float, fp, fp, u8p, i32p]
+    L.hsr_batch_step_dev.argtypes = [vp, vp, C.c_int, C.c_int, C.c_float, vp, vp, vp, vp]
+    L.hsr_batch_body_xpos.argtypes = [vp, C.c_int, fp]
+    L.hsr_batch_bad_state.argtypes = [vp, u8p]
+    L.hsr_batch_get_field.argtypes = [vp, C.c_int, fp]
+    L.hsr_batch_set_profiling.argtypes = [vp, C.c_int]
+    L.hsr_batch_last_timing.argtypes = [vp, fp, fp, C.POINTER(C.c_int)]
+    L.hsr_batch_set_graph.argtypes = [vp, C.c_int]
+    _lib = L
+    return L
+
+
+def _fp(a):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _f32(a, shape=None):
+    if a is None:
+        return None
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    if shape is not None:
+        assert a.shape == tuple(shape), f"expected shape {tuple(shape)}, got {a.shape}"
+    return a
+
+
+def _check(L, rc):
+    if rc == 0:
+        return
+    msg = L.hsr_last_error().decode()
+    if rc == -3:
+        raise DependencyNotInstalled(f"libhsrsim: {msg}")
+    if rc == -2:
+        raise IOError(f"libhsrsim: {msg}")
+    if rc == -5:
+        raise MujocoException(f"libhsrsim: {msg}")
+    if rc == -4:
+        raise KeyError(msg)
+    raise AssertionError(f"libhsrsim: {msg}")
+
+
+class BatchSim:
+    """N independent simulations advanced in lockstep on one GPU.
+
+    Mirrors, per env, ``mujoco_py.MjSim``: ``step/forward/reset/get_state/set_state`` and the
+    ``sim.data`` fields the reference reads or writes (ctrl, qpos, qvel, mocap_pos, body xpos)."""
+
+    def __init__(self, model: Model, n_envs: int, device: int = 0):
+        self.model = model
+        self.n = int(n_envs)
+        self._L = L = load_library()
+        raw = model.to_bytes()
+        self._m = C.c_void_p()
+        _check(L, L.hsr_model_load(raw, len(raw), C.byref(self._m)))
+        self._b = C.c_void_p()
+        _check(L, L.hsr_batch_create(self._m, self.n, int(device), C.byref(self._b)))
+        self.nq, self.nv, self.nu = model.nq, model.nv, model.nu
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_b", None):
+            self._L.hsr_batch_destroy(self._b); self._b = None
+        if getattr(self, "_m", None):
+            self._L.hsr_model_destroy(self._m); self._m = None
+
+    __del__ = close
+
+    # -- sim.reset() (+ the qpos/mocap writes of reset_model) then forward
+    def reset(self, mask=None, qpos0=None, mocap=None):
+        m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
+        q = _f32(qpos0, (self.n, self.nq)); mc = _f32(mocap, (self.n, 3))
+        _check(self._L, self._L.hsr_batch_reset(self._b, None if m is None else m.ctypes.data_as(C.POINTER(C.c_uint8)), _fp(q), _fp(mc)))
+
+    def forward(self):
+        _check(self._L, self._L.hsr_batch_forward(self._b))
+
+    def get_state(self):
+        t = np.empty(self.n, np.float32); q = np.empty((self.n, self.nq), np.float32); v = np.empty((self.n, self.nv), np.float32)
+        _check(self._L, self._L.hsr_batch_get_state(self._b, _fp(t), _fp(q), _fp(v)))
+        return t, q, v
+
+    def set_state(self, time=None, qpos=None, qvel=None):
+        t = _f32(time, (self.n,)); q = _f32(qpos, (self.n, self.nq)); v = _f32(qvel, (self.n, self.nv))
+        _check(self._L, self._L.hsr_batch_set_state(self._b, _fp(t), _fp(q), _fp(v)))
+
+    def set_mocap(self, mocap):
+        _check(self._L, self._L.hsr_batch_set_mocap(self._b, _fp(_f32(mocap, (self.n, 3)))))
+
+    def set_warmstart(self, w):
+        _check(self._L, self._L.hsr_batch_set_warmstart(self._b, _fp(_f32(w, (self.n, self.nv)))))
+
+    def get_warmstart(self):
+        w = np.empty((self.n, self.nv), np.float32)
+        _check(self._L, self._L.hsr_batch_get_warmstart(self._b, _fp(w)))
+        return w
+
+    def step(self, ctrl, n_substeps, goal_body=-1, geofence=0.0):
+        """HSREnv.step for all envs -> (obs[N,nq+nv], reward[N], done[N] bool, nsteps[N])."""
+        c = _f32(ctrl, (self.n, self.nu))
+        obs = np.empty((self.n, self.nq + self.nv), np.float32); rew = np.empty(self.n, np.float32)
+        done = np.empty(self.n, np.uint8); ns = np.empty(self.n, np.int32)
+        _check(self._L, self._L.hsr_batch_step(self._b, _fp(c), int(n_substeps), int(goal_body), float(geofence), _fp(obs), _fp(rew),
+                                               done.ctypes.data_as(C.POINTER(C.c_uint8)), ns.ctypes.data_as(C.POINTER(C.c_int32))))
+        return obs, rew, done.astype(bool), ns
+
+    def step_dev(self, d_ctrl, n_substeps, goal_body, geofence, d_obs=None, d_reward=None, d_done=None, d_nsteps=None):
+        """Device-pointer variant (ints from tensor.data_ptr()); asynchronous on the batch stream."""
+        _check(self._L, self._L.hsr_batch_step_dev(self._b, d_ctrl, int(n_substeps), int(goal_body), float(geofence),
+                                                   d_obs, d_reward, d_done, d_nsteps))
+
+    def sync(self):
+        _check(self._L, self._L.hsr_batch_sync(self._b))
+
+    def body_xpos(self, body_id: int):
+        out = np.empty((self.n, 3), np.float32)
+        _check(self._L, self._L.hsr_batch_body_xpos(self._b, int(body_id), _fp(out)))
+        return out
+
+    def bad_state(self):
+        out = np.empty(self.n, np.uint8)
+        rc = self._L.hsr_batch_bad_state(self._b, out.ctypes.data_as(C.POINTER(C.c_uint8)))
+        return out.astype(bool), rc == -5
+
+    def get_field(self, field: int):
+        m = self.model
+        shapes = {F_XPOS: (self.n, m.nlink, 3), F_XMAT: (self.n, m.nlink, 3, 3), F_M: (self.n, m.nv, m.nv),
+                  F_QACC: (self.n, m.nv), F_QACC_SMOOTH: (self.n, m.nv), F_QFRC_SMOOTH: (self.n, m.nv),
+                  F_QFRC_CONSTRAINT: (self.n, m.nv), F_NCON: (self.n,), F_NEFC: (self.n,), F_NITER: (self.n,),
+                  F_CONTACT: (self.n, m.nslot, 7)}
+        out = np.empty(shapes[field], np.float32)
+        _check(self._L, self._L.hsr_batch_get_field(self._b, field, _fp(out)))
+        return out
+
+    def set_profiling(self, on: bool):
+        _check(self._L, self._L.hsr_batch_set_profiling(self._b, int(on)))
+
+    def set_graph(self, on: bool):
+        _check(self._L, self._L.hsr_batch_set_graph(self._b, int(on)))
+
+    def last_timing(self):
+        tot = C.c_float(0); k = (C.c_float * 3)(); n = (C.c_int * 3)()
+        _check(self._L, self._L.hsr_batch_last_timing(self._b, C.byref(tot), k, n))
+        return float(tot.value), [float(x) for x in k], [int(x) for x in n]

@@ -1,0 +1,104 @@
+/*
+ * hsrsim.h - C-ABI of libhsrsim.so: the MI355X-native batched replacement for the slice of
+ * mujoco_py that ethanabrooks/hsr-env touches on its hot path (HSREnv.step -> sim.step()).
+ *
+ * Every entry point cites the reference interface it replaces (paths relative to the reference
+ * repository root).  All functions return 0 on success or a negative HSR_E* code; they never
+ * throw across the ABI.  hsr_last_error() returns a thread-local message for the last failure.
+ * Host arrays are caller-owned, row-major, float32 unless stated; "dev" variants take device
+ * pointers (same layout) and do not synchronise the stream.
+ *
+ * A batch is NOT thread-safe; it owns one HIP stream and all device buffers (SoA [field][env]).
+ */
+#ifndef HSRSIM_H
+#define HSRSIM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HSR_OK 0
+#define HSR_EINVAL (-1)   /* bad argument / shape (reference: AssertionError, hsr/mujoco_env.py:88-89) */
+#define HSR_EBLOB (-2)    /* not a model blob (reference: IOError on a missing XML, hsr/mujoco_env.py:30-31) */
+#define HSR_EDEVICE (-3)  /* HIP runtime failure / no GPU (reference: DependencyNotInstalled, hsr/mujoco_env.py:12-15) */
+#define HSR_ENAME (-4)    /* unknown body / joint name */
+#define HSR_EBADSTATE (-5) /* some env hit a non-finite state (reference: mujoco_py.MujocoException) */
+
+typedef struct hsr_model hsr_model;
+typedef struct hsr_batch hsr_batch;
+
+/* indices for hsr_model_size() */
+enum hsr_size { HSR_NQ = 0, HSR_NV, HSR_NU, HSR_NLINK, HSR_NBODY, HSR_NGEOM, HSR_NPAIR, HSR_NMESHVERT,
+                HSR_NSLOT, HSR_NLIMIT, HSR_NCONMAX, HSR_NJMAX, HSR_NMOCAP };
+
+const char *hsr_last_error(void);
+
+/* ---- model: replaces mujoco_py.load_model_from_path (hsr/mujoco_env.py:33) on the XML produced by
+ *      hsr/util.py:87-182; the blob is emitted offline by hsr_env_amd/compiler.py ---------------- */
+int hsr_model_load(const void *blob, size_t len, hsr_model **out);
+void hsr_model_destroy(hsr_model *m);
+int hsr_model_size(const hsr_model *m, int which);                 /* sim.model.nq / nv / nu (hsr/mujoco_env.py:88-89) */
+double hsr_model_timestep(const hsr_model *m);                     /* sim.model.opt.timestep (hsr/mujoco_env.py:98) */
+int hsr_model_ctrlrange(const hsr_model *m, float *out /*[nu,2]*/); /* model.actuator_ctrlrange (hsr/mujoco_env.py:44) */
+int hsr_model_qpos0(const hsr_model *m, float *out /*[nq]*/);       /* sim.data.qpos after MjSim() (hsr/mujoco_env.py:49) */
+int hsr_model_body_id(const hsr_model *m, const char *name);       /* name lookup behind data.get_body_xpos (hsr/env.py:144,180,184) */
+int hsr_model_joint_qpos_addr(const hsr_model *m, const char *name, int *start, int *end); /* model.get_joint_qpos_addr (hsr/env.py:153) */
+
+/* ---- batch of N independent envs on one GPU: replaces N x mujoco_py.MjSim(model) (hsr/mujoco_env.py:34) */
+int hsr_batch_create(const hsr_model *m, int n_envs, int device_id, hsr_batch **out);
+void hsr_batch_destroy(hsr_batch *b);                              /* sim.__exit__ (hsr/env.py:209) */
+int hsr_batch_size(const hsr_batch *b);
+void *hsr_batch_stream(const hsr_batch *b);                        /* hipStream_t the batch launches on */
+int hsr_batch_sync(hsr_batch *b);
+
+/* sim.reset() + reset_model() writes (hsr/mujoco_env.py:83-85, hsr/env.py:158-177): for envs with
+ * mask[e] != 0 (all if mask == NULL): qpos <- qpos0[e] (model qpos0 if NULL), qvel <- 0, ctrl <- 0,
+ * warm start <- 0, time <- 0, mocap_pos <- mocap[e] (0 if NULL); then sim.forward(). */
+int hsr_batch_reset(hsr_batch *b, const uint8_t *mask, const float *qpos0 /*[N,nq]*/, const float *mocap /*[N,3]*/);
+
+/* sim.get_state() / sim.set_state(MjSimState(time,qpos,qvel,act,udd_state)) + forward
+ * (hsr/mujoco_env.py:87-94, hsr/env.py:69,150,175); act and udd_state are empty for this model */
+int hsr_batch_get_state(hsr_batch *b, float *time /*[N]*/, float *qpos /*[N,nq]*/, float *qvel /*[N,nv]*/);
+int hsr_batch_set_state(hsr_batch *b, const float *time, const float *qpos, const float *qvel);
+int hsr_batch_set_mocap(hsr_batch *b, const float *mocap /*[N,3]*/);   /* sim.data.mocap_pos[:] = ... (hsr/env.py:169) */
+int hsr_batch_set_warmstart(hsr_batch *b, const float *qacc_warmstart /*[N,nv]*/);
+int hsr_batch_get_warmstart(hsr_batch *b, float *qacc_warmstart /*[N,nv]*/);
+int hsr_batch_forward(hsr_batch *b);                               /* sim.forward() (hsr/env.py:176) */
+
+/* HSREnv.step (hsr/env.py:115-135) for all envs: ctrl[:] = action; up to n_substeps x { sim.step();
+ * done = |xpos(goal_body) - mocap_pos| < geofence; break if done }; obs = concat(qpos, qvel);
+ * reward = float(done).  goal_body < 0 reproduces `goals is None` (done stays 0).
+ * Outputs may be NULL.  nsteps (optional) receives the substeps each env actually ran. */
+int hsr_batch_step(hsr_batch *b, const float *ctrl /*[N,nu]*/, int n_substeps, int goal_body, float geofence,
+                   float *obs /*[N,nq+nv]*/, float *reward /*[N]*/, uint8_t *done /*[N]*/, int32_t *nsteps /*[N]*/);
+/* same with device pointers, asynchronous on hsr_batch_stream() */
+int hsr_batch_step_dev(hsr_batch *b, const float *d_ctrl, int n_substeps, int goal_body, float geofence,
+                       float *d_obs, float *d_reward, uint8_t *d_done, int32_t *d_nsteps);
+
+/* sim.data.get_body_xpos(name) for every env (hsr/env.py:144,180,184); valid after forward/step */
+int hsr_batch_body_xpos(hsr_batch *b, int body_id, float *out /*[N,3]*/);
+
+/* per-env error flags (non-finite or |q| > 1e10), the batched form of MuJoCo's mj_checkPos/Vel */
+int hsr_batch_bad_state(hsr_batch *b, uint8_t *out /*[N]*/);
+
+/* ---- introspection used by the parity tests (stage-by-stage comparison with the oracle) ------ */
+enum hsr_field { HSR_F_XPOS = 0 /*[N,nlink,3]*/, HSR_F_XMAT /*[N,nlink,9]*/, HSR_F_M /*[N,nv,nv]*/,
+                 HSR_F_QACC /*[N,nv]*/, HSR_F_QACC_SMOOTH /*[N,nv]*/, HSR_F_QFRC_SMOOTH /*[N,nv]*/,
+                 HSR_F_QFRC_CONSTRAINT /*[N,nv]*/, HSR_F_NCON /*[N] (as float)*/, HSR_F_NEFC /*[N]*/,
+                 HSR_F_CONTACT /*[N,nslot,7] pos3 normal3 dist; dist=+1 marks an empty slot*/,
+                 HSR_F_NITER /*[N]*/ };
+int hsr_batch_get_field(hsr_batch *b, int field, float *out);
+/* timing of the last hsr_batch_step*: total ms and per-kernel ms (HIP events on the batch stream);
+ * enable with hsr_batch_set_profiling(b, 1).  kernel order: kinematics, collide, solve */
+int hsr_batch_set_profiling(hsr_batch *b, int on);
+int hsr_batch_last_timing(hsr_batch *b, float *total_ms, float *kernel_ms /*[3]*/, int *launches /*[3]*/);
+/* use a captured hipGraph for the substep loop (default on) */
+int hsr_batch_set_graph(hsr_batch *b, int on);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HSRSIM_H */
