@@ -1,0 +1,221 @@
+#!/usr/bin/env python
+"""Headline benchmark: env-steps/s of the batched HSR stepper (BASELINE.json metric).
+
+One "step" = one env-step of every env on every rank: ctrl write, 300 substeps of h = 0.002 with the
+per-substep goal test / early exit (hsr/env.py:115-135), obs/reward/done, the `if done: reset()` of the
+reference's driver loop (hsr/control.py:73-75) and, for N > 1, one RCCL all-gather of obs/reward/done.
+Workload (config.workload): BASELINE config 3 - all 7 DOFs + 1 block, 8192 envs per GPU (weak scaling),
+synthetic inputs of SURVEY.md section 8d resident in HBM before the timed region.
+
+    python bench.py [--gpus N --steps K --warmup W]            (N > 1: launched by torch.distributed.run)
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+STEPS_PER_ACTION = 300
+GEOFENCE = 0.05
+HBM_PEAK_GBPS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def sample_inputs(m, n, seed, offset):
+    """Synthetic inputs of SURVEY.md 8d for global env ids [offset, offset+n): block start
+    (x,y) ~ U([-.1,.1]x[-.2,.2]), z = .422, yaw ~ U(-pi,pi); goal ~ U(same box) but at least
+    2*geofence from the block so that an early exit needs the robot to push the block there."""
+    rng = np.random.Generator(np.random.Philox(key=[seed, offset]))
+    nrob = m.nu
+    q = np.tile(m.qpos0, (n, 1))
+    nb = (m.nq - nrob) // 7
+    for b in range(nb):
+        a = nrob + 7 * b
+        yaw = rng.uniform(-np.pi, np.pi, n)
+        q[:, a] = rng.uniform(-0.1, 0.1, n)
+        q[:, a + 1] = rng.uniform(-0.2, 0.2, n) if nb == 1 else rng.uniform(-0.04, 0.04, n) + 0.13 * (b - (nb - 1) / 2)
+        q[:, a + 2] = 0.422
+        q[:, a + 3] = np.cos(yaw / 2); q[:, a + 4] = 0; q[:, a + 5] = 0; q[:, a + 6] = np.sin(yaw / 2)
+    goal = np.column_stack([rng.uniform(-0.1, 0.1, n), rng.uniform(-0.2, 0.2, n), np.full(n, 0.422)])
+    if nb:
+        for _ in range(50):
+            close = np.linalg.norm(goal[:, :2] - q[:, nrob:nrob + 2], axis=1) < 2 * GEOFENCE
+            if not close.any():
+                break
+            goal[close, 0] = rng.uniform(-0.1, 0.1, close.sum()); goal[close, 1] = rng.uniform(-0.2, 0.2, close.sum())
+    return q.astype(np.float32), goal.astype(np.float32)
+
+
+def cpu_baseline(m, q0, goal, ctrl, cores):
+    """Oracle (fp64 C restatement, OpenMP over envs) on the host cores, bounded sample of the same
+    workload: the first min(N, 64*cores) envs, as many env-steps as fit in ~12 s."""
+    from oracle import oracle as orc
+    n = min(q0.shape[0], 64 * cores)
+    qpos = q0[:n].astype(np.float64).copy(); qvel = np.zeros((n, m.nv)); warm = np.zeros((n, m.nv))
+    mocap = goal[:n].astype(np.float64).copy()
+    bid = m.body_id("block0") if "block0" in m.names["body"] else -1
+    t0 = time.perf_counter()
+    orc.batch_env_step(m, qpos, qvel, warm, ctrl[0][:n].astype(np.float64).copy(), mocap, STEPS_PER_ACTION, bid, GEOFENCE, cores)
+    t1 = time.perf_counter() - t0
+    reps = int(max(1, min(len(ctrl) - 1, 12.0 / max(t1, 1e-3) - 1)))
+    t0 = time.perf_counter()
+    for k in range(reps):
+        orc.batch_env_step(m, qpos, qvel, warm, ctrl[1 + k][:n].astype(np.float64).copy(), mocap, STEPS_PER_ACTION, bid, GEOFENCE, cores)
+    dt = time.perf_counter() - t0
+    return dict(value=n * reps / dt, unit="env-steps/s", cores=cores, kind="port",
+                sample=f"{n} envs x {reps} env-steps x {STEPS_PER_ACTION} substeps of the same workload, "
+                       f"oracle/hsr_oracle.c fp64 with OpenMP over envs ({cores} threads); stand-in for CPU mujoco-py, "
+                       "which is not installable here")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--envs-per-gpu", type=int, default=8192)
+    ap.add_argument("--config", default="cfg3")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    from hsr_env_amd.compiler import load_config
+    from hsr_env_amd.sim import BatchSim
+    from hsr_env_amd import dist as hdist
+
+    rank, world, local_rank = hdist.rank_world()
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    m = load_config(args.config)
+    n = args.envs_per_gpu
+    offset = rank * n
+    K, W = args.steps, args.warmup
+    total = K + W + 1                       # +1 profiled env-step after the timed region
+    q0, goal = sample_inputs(m, n, 0, offset)
+    rng = np.random.Generator(np.random.Philox(key=[1, offset]))
+    lo, hi = m.act_ctrlrange[:, 0].astype(np.float32), m.act_ctrlrange[:, 1].astype(np.float32)
+    ctrl_host = [rng.uniform(lo, hi, (n, m.nu)).astype(np.float32) for _ in range(total)]
+    reset_host = [sample_inputs(m, n, 2 + k, offset) for k in range(total)]
+
+    sim = BatchSim(m, n, device=local_rank)
+    if args.no_graph:
+        sim.set_graph(False)
+    sim.reset(qpos0=q0, mocap=goal)
+    # everything the timed region consumes is resident in HBM before it starts
+    d_ctrl = [torch.from_numpy(c).to(dev) for c in ctrl_host]
+    d_rq = [torch.from_numpy(r[0]).to(dev) for r in reset_host]
+    d_rg = [torch.from_numpy(r[1]).to(dev) for r in reset_host]
+    nobs = m.nq + m.nv
+    d_obs = torch.empty((n, nobs), dtype=torch.float32, device=dev)
+    d_rew = torch.empty(n, dtype=torch.float32, device=dev)
+    d_done = torch.empty(n, dtype=torch.uint8, device=dev)
+    d_ns = torch.empty(n, dtype=torch.int32, device=dev)
+    d_pack = torch.empty((n, nobs + 2), dtype=torch.float32, device=dev)
+    d_all = torch.empty((world * n, nobs + 2), dtype=torch.float32, device=dev) if world > 1 else None
+    bid = m.body_id("block0") if "block0" in m.names["body"] else -1
+    substeps_done = torch.zeros((), dtype=torch.int64, device=dev)
+    dones = torch.zeros((), dtype=torch.int64, device=dev)
+
+    # torch ops (reductions, packing, the RCCL all-gather) are enqueued on the batch's own stream
+    ext = torch.cuda.ExternalStream(sim.stream_ptr(), device=dev)
+    torch.cuda.set_stream(ext)
+
+    def env_step(k):
+        sim.step_dev(d_ctrl[k].data_ptr(), STEPS_PER_ACTION, bid, GEOFENCE, d_obs.data_ptr(), d_rew.data_ptr(),
+                     d_done.data_ptr(), d_ns.data_ptr())
+        sim.reset_dev(None, d_rq[k].data_ptr(), d_rg[k].data_ptr())     # `if done: env.reset()`
+        if world > 1:
+            d_pack[:, :nobs] = d_obs; d_pack[:, nobs] = d_rew; d_pack[:, nobs + 1] = d_done
+            dist.all_gather_into_tensor(d_all, d_pack)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for k in range(W):
+        env_step(k)
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(W, W + K):
+        env_step(k)
+        substeps_done += d_ns.sum()     # on torch's stream; ordered by the device-wide sync below
+        dones += d_done.sum()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # per-kernel average launch duration (HIP events on the batch stream), one extra env-step
+    sim.set_profiling(True)
+    sim.step_dev(d_ctrl[W + K].data_ptr(), STEPS_PER_ACTION, bid, GEOFENCE, d_obs.data_ptr(), d_rew.data_ptr(), d_done.data_ptr(), d_ns.data_ptr())
+    sim.sync()
+    tot_ms, k_ms, k_n = sim.last_timing()
+    sim.set_profiling(False)
+    names = ["k_kinematics", "k_collide", "k_solve"]
+    dom = int(np.argmax(k_ms))
+    avg_us = 1e3 * k_ms[dom] / max(k_n[dom], 1)
+    # algorithmic bytes: fp32 state stream per substep per env = 4*(2nq+2nv+nu+3) (SURVEY.md 8d / BASELINE.md 3)
+    bytes_per_substep_env = 4 * (2 * m.nq + 2 * m.nv + m.nu + 3)
+    bytes_per_launch = bytes_per_substep_env * n
+    achieved = bytes_per_launch / (avg_us * 1e-6) / 1e9
+    traffic = None
+    pmc = ROOT / "profiles" / "pmc_summary.json"
+    if pmc.exists():
+        try:
+            traffic = json.loads(pmc.read_text()).get(names[dom], {}).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    value = world * n * K / dt
+    mean_substeps = float(substeps_done.item()) / (n * K)
+    bad, any_bad = sim.bad_state()
+
+    out = {
+        "metric": "env-steps/sec (whole node), HSR+1-block, steps_per_action=300, 8192 envs",
+        "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
+        "ms_per_step": 1e3 * dt / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"BASELINE config 3: {args.config} all 7 DOFs + 1 block, {n} envs per GPU x {world} GPU(s), "
+                               f"steps_per_action={STEPS_PER_ACTION}, geofence={GEOFENCE}, ctrl~U(ctrlrange) per env-step, done envs reset",
+                   "envs_per_gpu": n, "global_envs": world * n, "substeps_per_env_step": STEPS_PER_ACTION,
+                   "mean_substeps_executed": mean_substeps, "done_fraction": float(dones.item()) / (n * K),
+                   "parallelism": f"env-shard x{world}" + (" + all-gather(obs,reward,done)" if world > 1 else ""),
+                   "substeps_per_s": value * mean_substeps, "hipgraph": not args.no_graph, "bad_envs": int(bad.sum())},
+        "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                     "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_us": avg_us,
+                     "kernel_ms_per_env_step": dict(zip(names, k_ms)), "launches_per_env_step": dict(zip(names, k_n)),
+                     "note": "state stays L2/MALL-resident; the path is FP32-VALU/latency bound, not HBM bound (SURVEY.md 8d)"},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        out["cpu_baseline"] = cpu_baseline(m, q0, goal, ctrl_host, cores)
+    elif rank == 0:
+        out["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(out))
+    sim.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

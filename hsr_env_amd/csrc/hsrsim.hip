@@ -153,6 +153,7 @@ struct hsr_batch {
     DevModel dm{};
     DevState ds{};
     std::vector<void *> allocs;
+    float *d_qpos0 = nullptr;      // model qpos0 on the device
     float *d_stage = nullptr;      // staging for host-pointer API: max(N*(nq+nv), ...) floats
     size_t stage_floats = 0;
     uint8_t *d_stage_u8 = nullptr;
@@ -382,6 +383,7 @@ extern "C" int hsr_batch_create(const hsr_model *m, int n_envs, int device_id, h
     float *d_q0;
     if ((rc = dalloc(b, &d_q0, (size_t)d.nq))) return rc;
     HIPCHK(hipMemcpy(d_q0, m->qpos0.data(), d.nq * sizeof(float), hipMemcpyHostToDevice));
+    b->d_qpos0 = d_q0;
     hipLaunchKernelGGL(k_reset, grid1(N), dim3(256), 0, b->stream, b->dm, b->ds, (const uint8_t *)nullptr, (const float *)nullptr, (const float *)d_q0, (const float *)nullptr);
     HIPCHK(hipStreamSynchronize(b->stream));
     *out = b;
@@ -432,9 +434,8 @@ extern "C" int hsr_batch_reset(hsr_batch *b, const uint8_t *mask, const float *q
     HIPCHK(hipSetDevice(b->device));
     const size_t N = b->N;
     const int nq = b->dm.nq;
-    float *d_q = nullptr, *d_m = nullptr, *d_q0m = b->d_stage;
-    size_t off = (size_t)nq;
-    HIPCHK(hipMemcpyAsync(d_q0m, b->model->qpos0.data(), nq * sizeof(float), hipMemcpyHostToDevice, b->stream));
+    float *d_q = nullptr, *d_m = nullptr, *d_q0m = b->d_qpos0;
+    size_t off = 0;
     if (qpos0) { d_q = b->d_stage + off; off += N * nq; HIPCHK(hipMemcpyAsync(d_q, qpos0, N * nq * sizeof(float), hipMemcpyHostToDevice, b->stream)); }
     if (mocap) { d_m = b->d_stage + off; off += N * 3; HIPCHK(hipMemcpyAsync(d_m, mocap, N * 3 * sizeof(float), hipMemcpyHostToDevice, b->stream)); }
     if (off > b->stage_floats) return fail(HSR_EINVAL, "staging overflow in reset");
@@ -444,6 +445,23 @@ extern "C" int hsr_batch_reset(hsr_batch *b, const uint8_t *mask, const float *q
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(b->stream));
     return hsr_batch_forward(b);
+}
+
+// device-pointer reset: envs with d_mask[e] != 0 (or, when d_mask == NULL, the envs whose done flag was
+// latched by the last step) restart from d_qpos0[e] / d_mocap[e]; asynchronous; followed by forward.
+__global__ void k_mask_from_done(DevState s, uint8_t *mask) {
+    int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < s.N) mask[e] = (uint8_t)(s.done[e] != 0);
+}
+extern "C" int hsr_batch_reset_dev(hsr_batch *b, const uint8_t *d_mask, const float *d_qpos0, const float *d_mocap) {
+    HIPCHK(hipSetDevice(b->device));
+    const size_t N = b->N;
+    if (!d_mask) { hipLaunchKernelGGL(k_mask_from_done, grid1(N), dim3(256), 0, b->stream, b->ds, b->d_stage_u8); d_mask = b->d_stage_u8; }
+    hipLaunchKernelGGL(k_reset, grid1(N), dim3(256), 0, b->stream, b->dm, b->ds, d_mask, d_qpos0, (const float *)b->d_qpos0, d_mocap);
+    hipLaunchKernelGGL(k_clear_done, grid1(N), dim3(256), 0, b->stream, b->ds);
+    launch_substep(b, 0, -1, 0.f, 0, b->stream, false);
+    HIPCHK(hipGetLastError());
+    return HSR_OK;
 }
 
 static int to_device_soa(hsr_batch *b, float *dst, const float *host, int rows) {

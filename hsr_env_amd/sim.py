@@ -31,7 +31,7 @@ EXPORTS = [
     "hsr_last_error", "hsr_model_load", "hsr_model_destroy", "hsr_model_size", "hsr_model_timestep",
     "hsr_model_ctrlrange", "hsr_model_qpos0", "hsr_model_body_id", "hsr_model_joint_qpos_addr",
     "hsr_batch_create", "hsr_batch_destroy", "hsr_batch_size", "hsr_batch_stream", "hsr_batch_sync",
-    "hsr_batch_reset", "hsr_batch_get_state", "hsr_batch_set_state", "hsr_batch_set_mocap",
+    "hsr_batch_reset", "hsr_batch_reset_dev", "hsr_batch_get_state", "hsr_batch_set_state", "hsr_batch_set_mocap",
     "hsr_batch_set_warmstart", "hsr_batch_get_warmstart", "hsr_batch_forward", "hsr_batch_step",
     "hsr_batch_step_dev", "hsr_batch_body_xpos", "hsr_batch_bad_state", "hsr_batch_get_field",
     "hsr_batch_set_profiling", "hsr_batch_last_timing", "hsr_batch_set_graph",
@@ -68,6 +68,7 @@ def load_library():
     L.hsr_batch_stream.argtypes = [vp]; L.hsr_batch_stream.restype = vp
     L.hsr_batch_sync.argtypes = [vp]
     L.hsr_batch_reset.argtypes = [vp, u8p, fp, fp]
+    L.hsr_batch_reset_dev.argtypes = [vp, vp, vp, vp]
     L.hsr_batch_get_state.argtypes = [vp, fp, fp, fp]
     L.hsr_batch_set_state.argtypes = [vp, fp, fp, fp]
     L.hsr_batch_set_mocap.argtypes = [vp, fp]
@@ -146,6 +147,10 @@ class BatchSim:
         q = _f32(qpos0, (self.n, self.nq)); mc = _f32(mocap, (self.n, 3))
         _check(self._L, self._L.hsr_batch_reset(self._b, None if m is None else m.ctypes.data_as(C.POINTER(C.c_uint8)), _fp(q), _fp(mc)))
 
+    def reset_dev(self, d_mask, d_qpos0, d_mocap):
+        """Device-pointer masked reset (d_mask None/0 -> envs whose done flag was latched); async."""
+        _check(self._L, self._L.hsr_batch_reset_dev(self._b, d_mask, d_qpos0, d_mocap))
+
     def forward(self):
         _check(self._L, self._L.hsr_batch_forward(self._b))
 
@@ -185,6 +190,10 @@ class BatchSim:
 
     def sync(self):
         _check(self._L, self._L.hsr_batch_sync(self._b))
+
+    def stream_ptr(self) -> int:
+        """hipStream_t of the batch (wrap with torch.cuda.ExternalStream to order torch ops after steps)."""
+        return int(self._L.hsr_batch_stream(self._b))
 
     def body_xpos(self, body_id: int):
         out = np.empty((self.n, 3), np.float32)

@@ -59,6 +59,10 @@ int hsr_batch_sync(hsr_batch *b);
  * warm start <- 0, time <- 0, mocap_pos <- mocap[e] (0 if NULL); then sim.forward(). */
 int hsr_batch_reset(hsr_batch *b, const uint8_t *mask, const float *qpos0 /*[N,nq]*/, const float *mocap /*[N,3]*/);
 
+/* same for device pointers, asynchronous; d_mask == NULL means "the envs whose done flag the last step
+ * latched" - the batched form of `if done: env.reset()` (hsr/control.py:73-75) */
+int hsr_batch_reset_dev(hsr_batch *b, const uint8_t *d_mask, const float *d_qpos0, const float *d_mocap);
+
 /* sim.get_state() / sim.set_state(MjSimState(time,qpos,qvel,act,udd_state)) + forward
  * (hsr/mujoco_env.py:87-94, hsr/env.py:69,150,175); act and udd_state are empty for this model */
 int hsr_batch_get_state(hsr_batch *b, float *time /*[N]*/, float *qpos /*[N,nq]*/, float *qvel /*[N,nv]*/);
