@@ -320,7 +320,7 @@ _ARRAY_FIELDS = [
     "sizes", "opt",
     "qpos0",
     "link_parent", "link_pos", "link_quat", "link_dofadr", "link_dofnum", "link_qposadr",
-    "link_free", "link_mass", "link_com", "link_inertia",
+    "link_free", "link_mass", "link_com", "link_inertia", "link_dofmask",
     "dof_link", "dof_type", "dof_axis", "dof_pos", "dof_parent", "dof_damping", "dof_qposadr",
     "dof_invweight0", "dof_limited", "dof_range", "dof_solref", "dof_solimp",
     "body_link", "body_pos", "body_quat", "body_mocap",
@@ -747,8 +747,25 @@ def compile_model(dofs: Sequence[str] = ("slide_x", "slide_y"), n_blocks: int = 
     act_ctrlrange = np.array([_vec(a.get("ctrlrange"), 2, [0, 0]) for a in acts]).reshape(-1, 2)
     act_forcerange = np.array([_vec(a.get("forcerange"), 2, [0, 0]) for a in acts]).reshape(-1, 2)
 
+    # bit k of link_dofmask[l] is set when dof k lies on the path from link l to the root
+    link_dofmask = np.zeros(nlink, dtype=np.int32)
+    for l in range(1, nlink):
+        k = link_dofadr[l] + link_dofnum[l] - 1
+        while k >= 0:
+            link_dofmask[l] |= (1 << k)
+            k = dof["parent"][k]
+    # device-friendly buffer caps (the XML asks for nconmax=100 njmax=500, world.xml:44, which MuJoCo only
+    # uses as buffer sizes): contacts beyond nconmax / rows beyond njmax are dropped identically by the
+    # oracle and the HIP path.  One lane group (16 or 32 lanes) serves an env, so caps are multiples of it.
+    group = 16 if nv <= 16 else 32
+    eff_nconmax = group
+    eff_njmax = {True: 48, False: 96}[nv <= 16]
+    meta["xml_nconmax_njmax"] = [opt["nconmax"], opt["njmax"]]
+    opt["nconmax"], opt["njmax"] = eff_nconmax, eff_njmax
+
     arrays = dict(
         qpos0=np.array(qpos0),
+        link_dofmask=link_dofmask,
         link_parent=link_parent,
         link_pos=np.array([lk["pos"] for lk in links]), link_quat=np.array([lk["quat"] for lk in links]),
         link_dofadr=link_dofadr, link_dofnum=link_dofnum, link_qposadr=link_qposadr, link_free=link_free,

@@ -72,6 +72,64 @@ __global__ void k_kinematics(DevModel m, DevState s) {
         xpos.set3(l, pos);
         xmat.setm(l, mat);
     }
+    // ---- link velocities / bias accelerations (qacc = 0) and the per-link wrench of mj_rne:
+    //      F = m (a_com - g), N = I alpha + w x I w  (consumed by the solve kernel as bias = J^T [F; N])
+    View qvel{s.qvel + e, N}, ws{s.ws + e, N}, ld{s.link_dyn + e, N};
+    View lw = ws.sub(s.o_lw), lvo = ws.sub(s.o_lvo), lal = ws.sub(s.o_lal), lao = ws.sub(s.o_lao);
+    lw.set3(0, mk3(0, 0, 0)); lvo.set3(0, mk3(0, 0, 0)); lal.set3(0, mk3(0, 0, 0)); lao.set3(0, mk3(0, 0, 0));
+    for (int k = 0; k < 15; k++) ld[k] = 0;
+    for (int l = 1; l < m.nlink; l++) {
+        const int d0 = m.link_dofadr[l];
+        const m3 R = xmat.getm(l);
+        const v3 xl = xpos.get3(l);
+        v3 w, vo, al, ao;
+        if (m.link_free[l]) {
+            vo = mk3(qvel[d0], qvel[d0 + 1], qvel[d0 + 2]);
+            w = mulmv(R, mk3(qvel[d0 + 3], qvel[d0 + 4], qvel[d0 + 5]));
+            al = mk3(0, 0, 0); ao = mk3(0, 0, 0);
+        } else {
+            const int p = m.link_parent[l];
+            const v3 wp = lw.get3(p), vop = lvo.get3(p), alp = lal.get3(p), aop = lao.get3(p);
+            const v3 r = xl - xpos.get3(p);
+            w = wp; al = alp;
+            vo = vop + cross(wp, r);
+            ao = aop + cross(alp, r) + cross(wp, cross(wp, r));
+            for (int k = d0; k < d0 + m.link_dofnum[l]; k++) {
+                const float qd = qvel[k];
+                if (m.dof_type[k] == DOF_SLIDE) {
+                    const v3 sx = lin.get3(k);
+                    vo = vo + sx * qd;
+                    ao = ao + cross(wp, sx) * (2 * qd);
+                } else {
+                    const v3 a = ang.get3(k);
+                    const v3 rho = xl - anc.get3(k), rc = r - rho;
+                    const v3 wl = w + a * qd, all = al + cross(w, a) * qd;
+                    const v3 ac = aop + cross(alp, rc) + cross(wp, cross(wp, rc));
+                    const v3 vc = vop + cross(wp, rc);
+                    ao = ac + cross(all, rho) + cross(wl, cross(wl, rho));
+                    vo = vc + cross(wl, rho);
+                    w = wl; al = all;
+                }
+            }
+        }
+        lw.set3(l, w); lvo.set3(l, vo); lal.set3(l, al); lao.set3(l, ao);
+        const float *li = m.link_inertia + 6 * l;
+        m3 Il, Rt;
+        Il.a[0] = li[0]; Il.a[1] = li[3]; Il.a[2] = li[4]; Il.a[3] = li[3]; Il.a[4] = li[1]; Il.a[5] = li[5]; Il.a[6] = li[4]; Il.a[7] = li[5]; Il.a[8] = li[2];
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int j = 0; j < 3; j++) Rt.a[3 * i + j] = R.a[3 * j + i];
+        const m3 I = mulmm(mulmm(R, Il), Rt);
+        const v3 com = xl + mulmv(R, ld3(m.link_com, l)), rc = com - xl;
+        const v3 acom = ao + cross(al, rc) + cross(w, cross(w, rc));
+        const v3 F = (acom - mk3(0, 0, m.gravz)) * m.link_mass[l];
+        const v3 Nt = mulmv(I, al) + cross(w, mulmv(I, w));
+        const int b = 15 * l;
+        ld[b] = com.x; ld[b + 1] = com.y; ld[b + 2] = com.z;
+        ld[b + 3] = I.a[0]; ld[b + 4] = I.a[4]; ld[b + 5] = I.a[8]; ld[b + 6] = I.a[1]; ld[b + 7] = I.a[2]; ld[b + 8] = I.a[5];
+        ld[b + 9] = F.x; ld[b + 10] = F.y; ld[b + 11] = F.z; ld[b + 12] = Nt.x; ld[b + 13] = Nt.y; ld[b + 14] = Nt.z;
+    }
 }
 
 // ------------------------------------------------------------------ collision (a-2.3)

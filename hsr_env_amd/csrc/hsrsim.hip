@@ -17,6 +17,7 @@
 #include "collide.h"
 #include "model.h"
 #include "solve.h"
+#include "solve_g.h"
 
 static thread_local char g_err[512] = "";
 static int fail(int code, const char *fmt, const char *detail = "") {
@@ -160,6 +161,9 @@ struct hsr_batch {
     int32_t *d_stage_i32 = nullptr;
     int hot_threads = 64;
     size_t hot_lds_bytes = 0;
+    int solver = 1;                // 0: one lane per env (solve.h), 1: lane group per env (solve_g.h)
+    int group = 16;
+    size_t group_lds_bytes = 0;
     bool use_graph = true, profiling = false;
     std::map<GraphKey, hipGraphExec_t> graphs;
     float last_total_ms = 0, last_kernel_ms[3] = {0, 0, 0};
@@ -329,7 +333,7 @@ extern "C" int hsr_batch_create(const hsr_model *m, int n_envs, int device_id, h
 #define UI(f) if ((rc = upload_i(b, &d.f, m, #f))) { return rc; }
 #define UF(f) if ((rc = upload_f(b, &d.f, m, #f))) { return rc; }
     UI(link_parent) UI(link_dofadr) UI(link_dofnum) UI(link_qposadr) UI(link_free)
-    UF(link_pos) UF(link_mass) UF(link_com) UF(link_inertia)
+    UF(link_pos) UF(link_mass) UF(link_com) UF(link_inertia) UI(link_dofmask)
     UI(dof_link) UI(dof_type) UI(dof_parent) UI(dof_qposadr) UI(dof_limited)
     UF(dof_axis) UF(dof_pos) UF(dof_damping) UF(dof_invweight0) UF(dof_range) UF(dof_solref) UF(dof_solimp)
     UI(body_link) UI(body_mocap) UF(body_pos)
@@ -351,7 +355,7 @@ extern "C" int hsr_batch_create(const hsr_model *m, int n_envs, int device_id, h
 #define DA(field, rows) if ((rc = dalloc(b, &s.field, (size_t)(rows) * N))) return rc;
     DA(qpos, d.nq) DA(qvel, d.nv) DA(ctrl, d.nu) DA(mocap, 3) DA(warm, d.nv) DA(time, 1)
     DA(done, 1) DA(bad, 1) DA(nsteps, 1)
-    DA(xpos, 3 * d.nlink) DA(xmat, 9 * d.nlink) DA(dof_ang, 3 * d.nv) DA(dof_lin, 3 * d.nv) DA(dof_anchor, 3 * d.nv)
+    DA(xpos, 3 * d.nlink) DA(xmat, 9 * d.nlink) DA(dof_ang, 3 * d.nv) DA(dof_lin, 3 * d.nv) DA(dof_anchor, 3 * d.nv) DA(link_dyn, 15 * d.nlink)
     DA(con, 7 * d.nslot) DA(ncon_pair, d.npair)
     DA(M, d.nM) DA(qacc, d.nv) DA(qacc_smooth, d.nv) DA(qfrc_smooth, d.nv) DA(qfrc_constraint, d.nv)
     DA(ncon, 1) DA(nefc, 1) DA(niter, 1)
@@ -373,6 +377,20 @@ extern "C" int hsr_batch_create(const hsr_model *m, int n_envs, int device_id, h
     if (!s.hot_in_lds) b->hot_lds_bytes = 0;
     else if (b->hot_lds_bytes > 64 * 1024)
         HIPCHK(hipFuncSetAttribute((const void *)k_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->hot_lds_bytes));
+    // cooperative solver geometry: 16 lanes per env when nv <= 16, else 32
+    b->group = d.nv <= 16 ? 16 : 32;
+    {
+        const char *sv = getenv("HSR_SOLVER");
+        b->solver = (sv && strcmp(sv, "v1") == 0) ? 0 : 1;
+        if (d.nv > 32 || d.nlink > NLMAX || d.nconmax > b->group) b->solver = 0;
+        const int total = b->group == 16 ? SolveLayout<16>(d.njmax).total : SolveLayout<32>(d.njmax).total;
+        b->group_lds_bytes = (size_t)total * (64 / b->group) * sizeof(float);
+        if (b->group_lds_bytes > 160 * 1024) b->solver = 0;
+        if (b->solver && b->group_lds_bytes > 48 * 1024) {
+            if (b->group == 16) HIPCHK(hipFuncSetAttribute((const void *)k_solve_g<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->group_lds_bytes));
+            else HIPCHK(hipFuncSetAttribute((const void *)k_solve_g<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->group_lds_bytes));
+        }
+    }
     b->stage_floats = N * (size_t)(std::max(std::max(d.nq + d.nv, 7 * d.nslot), std::max(d.nv * d.nv, 9 * d.nlink)) + d.nu + d.nq + d.nv + 4) + 16;
     if ((rc = dalloc(b, &b->d_stage, b->stage_floats))) return rc;
     if ((rc = dalloc(b, &b->d_stage_u8, N))) return rc;
@@ -417,7 +435,9 @@ static void launch_substep(hsr_batch *b, int mode, int goal_body, float geofence
     rec();
     if (b->dm.npair > 0) hipLaunchKernelGGL(k_collide, dim3((N + 63) / 64, b->dm.npair), dim3(64), 0, st, b->dm, b->ds);
     rec();
-    hipLaunchKernelGGL(k_solve, dim3((N + 63) / 64), dim3(64), b->hot_lds_bytes, st, b->dm, b->ds, mode, goal_body, geofence, debug);
+    if (b->solver == 0) hipLaunchKernelGGL(k_solve, dim3((N + 63) / 64), dim3(64), b->hot_lds_bytes, st, b->dm, b->ds, mode, goal_body, geofence, debug);
+    else if (b->group == 16) hipLaunchKernelGGL(k_solve_g<16>, dim3((N + 3) / 4), dim3(64), b->group_lds_bytes, st, b->dm, b->ds, mode, goal_body, geofence, debug);
+    else hipLaunchKernelGGL(k_solve_g<32>, dim3((N + 1) / 2), dim3(64), b->group_lds_bytes, st, b->dm, b->ds, mode, goal_body, geofence, debug);
     rec();
 }
 

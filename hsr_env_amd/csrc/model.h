@@ -13,6 +13,7 @@ struct DevModel {
     int iterations, ls_iterations, mpr_iterations, any_damping;
     const int *link_parent, *link_dofadr, *link_dofnum, *link_qposadr, *link_free;
     const float *link_pos, *link_mat, *link_mass, *link_com, *link_inertia;
+    const int *link_dofmask;
     const int *dof_link, *dof_type, *dof_parent, *dof_qposadr, *dof_limited;
     const float *dof_axis, *dof_pos, *dof_damping, *dof_invweight0, *dof_range, *dof_solref, *dof_solimp;
     const int *body_link, *body_mocap;
@@ -33,6 +34,8 @@ struct DevState {
     int *done, *bad, *nsteps;
     // kinematics outputs
     float *xpos, *xmat, *dof_ang, *dof_lin, *dof_anchor;
+    // per-link dynamics terms from the kinematics kernel: com(3) Iworld(6: xx yy zz xy xz yz) F(3) N(3)
+    float *link_dyn;
     // collision outputs: contact slots (7 floats: pos, normal, dist) and per-pair counts
     float *con;
     int *ncon_pair;

@@ -470,7 +470,8 @@ __global__ void __launch_bounds__(64) k_solve(DevModel m, DevState s, int mode, 
             const float gtol = tol * m.ls_tolerance * snorm / scale;
             float dp, hp, lo = 0, hi = -1;
             ls_eval(m, c, 0.f, g1, g2, dp, hp);
-            if (dp >= 0 || hp <= 0) break;
+            // fp32 termination on the Newton decrement (predicted decrease), see solve_g.h
+            if (dp >= 0 || hp <= 0 || scale * 0.5f * (-dp) < tol) break;
             float alpha = -dp / hp;
             for (int it = 0; it < m.ls_iterations; it++) {
                 ls_eval(m, c, alpha, g1, g2, dp, hp);
@@ -483,9 +484,7 @@ __global__ void __launch_bounds__(64) k_solve(DevModel m, DevState s, int mode, 
             }
             if (!(alpha > 0)) break;
             for (int i = 0; i < nv; i++) h.qacc[i] += alpha * h.search[i];
-            const float oldcost = cost;
             cost = eval_at(m, c, h, h.qacc);
-            if (scale * (oldcost - cost) < tol) { iter++; break; }
         }
         for (int i = 0; i < nv; i++) {
             float sacc = 0;

@@ -1,0 +1,595 @@
+// Cooperative dynamics + constraint + Newton + Euler kernel: one group of G lanes (16 or 32) per env,
+// 64/G envs per single-wave workgroup, all per-env working data in LDS / registers.
+//
+// Why this shape on MI355X: at the benchmark size (8192 envs per GPU) one lane per env gives 128 waves
+// for 1024 SIMDs; 16 lanes per env give 2048 waves, the Jacobian / Hessian blocks (<= 48 x 13) fit the
+// 160 KB LDS of a CU several times over, and every cross-lane step is a width-16 shuffle or an LDS
+// broadcast read.  Lane roles change per phase: lane = dof column (inertia, gradient, Hessian rows,
+// Cholesky), lane = constraint row (J a, J search), lane = contact (cone evaluation).
+//
+// Same reference path as solve.h (mj_crb, mj_rne, actuation, mj_makeConstraint, mj_fwdConstraint Newton
+// with elliptic cones, mj_Euler, HSREnv.step goal test: hsr/env.py:115-135; SURVEY.md 8 a-2.2 .. a-4).
+#pragma once
+#include "devmath.h"
+#include "model.h"
+#include "solve.h"
+
+template <int G> __device__ __forceinline__ float gsum(float v) {
+#pragma unroll
+    for (int off = G / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, G);
+    return v;
+}
+template <int G> __device__ __forceinline__ int gscan_incl(int v, int c) {
+#pragma unroll
+    for (int off = 1; off < G; off <<= 1) { const int t = __shfl_up(v, off, G); if (c >= off) v += t; }
+    return v;
+}
+
+// in-register cooperative Cholesky: lane c holds row c (entries k <= c) of an SPD matrix; on return row c of L
+template <int G> __device__ __forceinline__ bool chol_g(float (&row)[G], int nv, int c) {
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < G; j++) {
+        if (j < nv) {
+            float ajj = __shfl(row[j], j, G);
+            if (!(ajj >= HSR_MINVAL)) { ok = false; ajj = 1.f; }
+            const float d = sqrtf(ajj), inv = 1.0f / d;
+            const float lcj = (c == j) ? d : row[j] * inv;
+            row[j] = lcj;
+#pragma unroll
+            for (int i = j + 1; i < G; i++) {
+                const float li = __shfl(lcj, i, G);
+                if (i <= c) row[i] -= lcj * li;
+            }
+        }
+    }
+    return ok;
+}
+// solve L L^T x = b with lane c holding row c of L and b_c; tile = G*(G+1) floats of LDS scratch.
+// Contains two workgroup barriers: must be called by every thread of the block.
+template <int G> __device__ __forceinline__ float chol_solve_g(const float (&row)[G], float b, int nv, int c, float *tile) {
+    float sacc = b, y = 0.f;
+#pragma unroll
+    for (int j = 0; j < G; j++) {
+        if (j < nv) {
+            const float yj = __shfl(sacc / row[j], j, G);
+            if (c == j) y = yj;
+            if (c > j) sacc -= row[j] * yj;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < G; k++) tile[c * (G + 1) + k] = (k <= c) ? row[k] : 0.f;
+    __syncthreads();
+    float lt[G];
+#pragma unroll
+    for (int k = 0; k < G; k++) lt[k] = tile[k * (G + 1) + c];      // L[k][c]
+    float s2 = y, x = 0.f;
+#pragma unroll
+    for (int j = G - 1; j >= 0; j--) {
+        if (j < nv) {
+            const float xj = __shfl(s2 / lt[j], j, G);
+            if (c == j) x = xj;
+            if (c < j) s2 -= lt[j] * xj;
+        }
+    }
+    return x;
+}
+
+// elliptic cone at residual x: cost, gradient g, and the Hessian in the form
+//   H = diag(dw) + Dm gn gn^T - k3 u u^T      (zone 0 top: all zero; 1 bottom: dw = D; 2 middle)
+struct ConeOut { float cost, Dm, k3; int zone; float g[6], dw[6], gn[6], u[6]; };
+__device__ __forceinline__ void cone_eval2(int dim, float mu, const float *fri, const float *D, const float *x, ConeOut &o) {
+    float U[6], T2 = 0;
+#pragma unroll
+    for (int j = 0; j < 6; j++) { o.g[j] = 0; o.dw[j] = 0; o.gn[j] = 0; o.u[j] = 0; }
+    o.cost = 0; o.Dm = 0; o.k3 = 0; o.zone = 0;
+    U[0] = x[0] * mu;
+    const float Nn = U[0];
+#pragma unroll
+    for (int j = 1; j < 6; j++) { U[j] = (j < dim) ? x[j] * fri[j - 1] : 0.f; T2 += U[j] * U[j]; }
+    const float T = sqrtf(T2);
+    if (Nn >= mu * T || (T <= 0 && Nn >= 0)) return;
+    if (mu * Nn + T <= 0 || (T <= 0 && Nn < 0)) {
+        o.zone = 1;
+#pragma unroll
+        for (int j = 0; j < 6; j++) if (j < dim) { o.cost += 0.5f * D[j] * x[j] * x[j]; o.g[j] = D[j] * x[j]; o.dw[j] = D[j]; }
+        return;
+    }
+    o.zone = 2;
+    const float Dm = D[0] / (mu * mu * (1 + mu * mu)), NT = Nn - mu * T, invT = 1.0f / T;
+    const float kappa = -Dm * NT * mu;
+    o.Dm = Dm; o.k3 = kappa * invT / T2;
+    o.gn[0] = mu;
+#pragma unroll
+    for (int j = 1; j < 6; j++) if (j < dim) {
+        o.gn[j] = -mu * U[j] * fri[j - 1] * invT;
+        o.u[j] = fri[j - 1] * U[j];
+        o.dw[j] = kappa * fri[j - 1] * fri[j - 1] * invT;
+    }
+#pragma unroll
+    for (int j = 0; j < 6; j++) o.g[j] = Dm * NT * o.gn[j];
+    o.cost = 0.5f * Dm * NT * NT;
+}
+
+// per-contact record in LDS (floats)
+enum { CR_POS = 0, CR_N = 3, CR_T1 = 6, CR_T2 = 9, CR_DIST = 12, CR_MU = 13, CR_PAIR = 14, CR_ADR = 15, CR_DIM = 16,
+       CR_ZONE = 17, CR_DM = 18, CR_K3 = 19, CR_GN = 20, CR_U = 26, CR_L1 = 32, CR_L2 = 33, CR_B = 34, CR_KD = 35, CR_SIZE = 36 };
+enum { NLMAX = 16, NVEC = 12 };
+
+template <int G> struct SolveLayout {
+    int R, RS, MS, oJ, oD, oAref, oJar, oJv, oGr, oDw, oVec, oM, oTile, oAng, oLin, oAnc, oLk, oCon, total;
+    __host__ __device__ SolveLayout(int rows) {
+        R = rows; RS = G + 4; MS = G + 1;
+        int o = 0;
+        oJ = o; o += R * RS;
+        oD = o; o += R; oAref = o; o += R; oJar = o; o += R; oJv = o; o += R; oGr = o; o += R; oDw = o; o += R;
+        oVec = o; o += NVEC * G;
+        oM = o; o += G * MS;
+        oTile = o; o += G * MS;
+        oAng = o; o += 3 * G; oLin = o; o += 3 * G; oAnc = o; o += 3 * G;
+        oLk = o; o += 15 * NLMAX;
+        oCon = o; o += CR_SIZE * G;
+        total = (o + 3) & ~3;
+    }
+};
+
+template <int G>
+__global__ void __launch_bounds__(64) k_solve_g(DevModel m, DevState s, int mode, int goal_body, float geofence, int debug) {
+    extern __shared__ __align__(16) float lds[];
+    constexpr int EPB = 64 / G;
+    const SolveLayout<G> L(m.njmax);
+    const int tid = threadIdx.x, g = tid / G, c = tid % G;
+    const int e_raw = blockIdx.x * EPB + g;
+    const bool valid = e_raw < s.N && !s.done[e_raw < s.N ? e_raw : 0];
+    if (!__syncthreads_or(valid)) return;
+    const int e = valid ? e_raw : 0;
+    const int N = s.N, nv = m.nv, R = L.R, RS = L.RS, MS = L.MS;
+    float *E = lds + (size_t)g * L.total;
+    float *J = E + L.oJ, *rD = E + L.oD, *rAref = E + L.oAref, *rJar = E + L.oJar, *rJv = E + L.oJv, *rGr = E + L.oGr, *rDw = E + L.oDw;
+    float *vQvel = E + L.oVec, *vQfs = vQvel + G, *vQas = vQfs + G, *vQacc = vQas + G, *vMa = vQacc + G, *vSearch = vMa + G,
+          *vWarm = vSearch + G, *vQfc = vWarm + G;
+    float *M = E + L.oM, *tile = E + L.oTile, *kAng = E + L.oAng, *kLin = E + L.oLin, *kAnc = E + L.oAnc, *lk = E + L.oLk, *con = E + L.oCon;
+    const bool isdof = c < nv;
+    int bad = 0;
+
+    // ---------------- phase A: stage per-env inputs into LDS
+    v3 a_c = mk3(0, 0, 0), l_c = mk3(0, 0, 0), n_c = mk3(0, 0, 0);
+    float qvel_c = 0, warm_c = 0;
+    if (isdof) {
+        qvel_c = s.qvel[(size_t)c * N + e]; warm_c = s.warm[(size_t)c * N + e];
+        View ang{s.dof_ang + e, N}, lin{s.dof_lin + e, N}, anc{s.dof_anchor + e, N};
+        a_c = ang.get3(c); l_c = lin.get3(c); n_c = anc.get3(c);
+        if (!(fabsf(qvel_c) <= 1e10f)) bad = 1;
+    }
+    vQvel[c] = qvel_c; vWarm[c] = warm_c;
+    kAng[3 * c] = a_c.x; kAng[3 * c + 1] = a_c.y; kAng[3 * c + 2] = a_c.z;
+    kLin[3 * c] = l_c.x; kLin[3 * c + 1] = l_c.y; kLin[3 * c + 2] = l_c.z;
+    kAnc[3 * c] = n_c.x; kAnc[3 * c + 1] = n_c.y; kAnc[3 * c + 2] = n_c.z;
+    if (c < m.nlink && c < NLMAX) {
+#pragma unroll
+        for (int k = 0; k < 15; k++) lk[15 * c + k] = s.link_dyn[(size_t)(15 * c + k) * N + e];
+    }
+#pragma unroll
+    for (int k = 0; k < G + 1; k++) M[c * MS + k] = 0.f;
+    __syncthreads();
+
+    // ---------------- phase B/C: inertia rows (a-2.2) and bias force (a-2.5), lane = dof
+    float bias_c = 0;
+    if (isdof) {
+        for (int l = 1; l < m.nlink; l++) {
+            if (!((m.link_dofmask[l] >> c) & 1)) continue;
+            const float *q = lk + 15 * l;
+            const v3 com = mk3(q[0], q[1], q[2]), F = mk3(q[9], q[10], q[11]), Nt = mk3(q[12], q[13], q[14]);
+            const v3 jpc = l_c + cross(a_c, com - n_c);
+            const v3 v = jpc * m.link_mass[l];
+            const v3 u = mk3(q[3] * a_c.x + q[6] * a_c.y + q[7] * a_c.z, q[6] * a_c.x + q[4] * a_c.y + q[8] * a_c.z, q[7] * a_c.x + q[8] * a_c.y + q[5] * a_c.z);
+            bias_c += dot(jpc, F) + dot(a_c, Nt);
+            for (int k = c; k >= 0; k = m.dof_parent[k]) {
+                const v3 ak = mk3(kAng[3 * k], kAng[3 * k + 1], kAng[3 * k + 2]);
+                const v3 jpk = mk3(kLin[3 * k], kLin[3 * k + 1], kLin[3 * k + 2]) + cross(ak, com - mk3(kAnc[3 * k], kAnc[3 * k + 1], kAnc[3 * k + 2]));
+                M[c * MS + k] += dot(jpk, v) + dot(ak, u);
+            }
+        }
+    }
+    float qfs_c = 0;
+    const float damp_c = isdof ? m.dof_damping[c] : 0.f;
+    if (isdof) {
+        qfs_c = -damp_c * qvel_c - bias_c;
+        for (int a = 0; a < m.nu; a++) if (m.act_dof[a] == c) {
+            const float q = s.qpos[(size_t)m.dof_qposadr[c] * N + e];
+            const float ct = fminf(fmaxf(s.ctrl[(size_t)a * N + e], m.act_ctrlrange[2 * a]), m.act_ctrlrange[2 * a + 1]);
+            float f = m.act_kp[a] * ct - m.act_kp[a] * m.act_gear[a] * q;
+            f = fminf(fmaxf(f, m.act_forcerange[2 * a]), m.act_forcerange[2 * a + 1]);
+            qfs_c += m.act_gear[a] * f;
+        }
+    }
+    vQfs[c] = qfs_c;
+    __syncthreads();
+    if (isdof) for (int k = m.dof_parent[c]; k >= 0; k = m.dof_parent[k]) M[k * MS + c] = M[c * MS + k];   // mirror
+    if (!isdof) M[c * MS + c] = 1.f;
+    __syncthreads();
+    if (debug && valid && isdof) for (int k = 0; k <= c; k++) s.M[(size_t)(c * (c + 1) / 2 + k) * N + e] = M[c * MS + k];
+
+    // ---------------- qacc_smooth = M^-1 qfrc_smooth
+    float Mrow[G];
+#pragma unroll
+    for (int k = 0; k < G; k++) Mrow[k] = M[c * MS + k];
+    float qas_c;
+    {
+        float Lr[G];
+#pragma unroll
+        for (int k = 0; k < G; k++) Lr[k] = Mrow[k];
+        if (!chol_g<G>(Lr, nv, c)) bad = 1;
+        qas_c = chol_solve_g<G>(Lr, qfs_c, nv, c, tile);
+        if (!isdof) qas_c = 0;
+    }
+    vQas[c] = qas_c;
+
+    // ---------------- phase E: constraint assembly (a-2.4)
+    // E1 joint limits, lane = dof, rows in dof order (lower side then upper side)
+    int nlim;
+    {
+        int a0 = 0, a1 = 0;
+        float dlo = 0, dhi = 0;
+        if (valid && isdof && m.dof_limited[c]) {
+            const float q = s.qpos[(size_t)m.dof_qposadr[c] * N + e];
+            if (!(fabsf(q) <= 1e10f)) bad = 1;
+            dlo = q - m.dof_range[2 * c]; dhi = m.dof_range[2 * c + 1] - q;
+            a0 = dlo < 0; a1 = dhi < 0;
+        }
+        const int incl = gscan_incl<G>(a0 + a1, c);
+        nlim = __shfl(incl, G - 1, G);
+        int r = incl - (a0 + a1);
+#pragma unroll
+        for (int side = 0; side < 2; side++) {
+            if ((side == 0 ? a0 : a1) && r < R) {
+                const float dist = side == 0 ? dlo : dhi, sg = side == 0 ? 1.f : -1.f;
+                const float imp = impedance(m.dof_solimp + 5 * c, dist);
+                const float dmax = fminf(fmaxf(m.dof_solimp[5 * c + 1], HSR_MINIMP), HSR_MAXIMP);
+                const float tc = m.dof_solref[2 * c], dr = m.dof_solref[2 * c + 1];
+                const float Kimp = imp / (dmax * dmax * tc * tc * dr * dr), B = 2.0f / (dmax * tc);
+                const float Rr = fmaxf((1 - imp) / imp * m.dof_invweight0[c], HSR_MINVAL);
+                for (int k = 0; k < G; k++) J[r * RS + k] = (k == c) ? sg : 0.f;
+                rAref[r] = -B * sg * qvel_c - Kimp * dist;
+                rD[r] = 1.0f / Rr;
+                r++;
+            }
+        }
+        if (nlim > R) nlim = R;
+    }
+    // E2 contact compaction in (pair, index) order: width-G scans over the per-pair counts (ballot-style)
+    int ncon = 0;
+    {
+        int base = 0;
+        for (int p0 = 0; p0 < m.npair; p0 += G) {
+            const int p = p0 + c;
+            const int cnt = (valid && p < m.npair) ? s.ncon_pair[(size_t)p * N + e] : 0;
+            const int incl = gscan_incl<G>(cnt, c);
+            const int tot = __shfl(incl, G - 1, G);
+            for (int i = 0; i < cnt; i++) {
+                const int ci = base + incl - cnt + i;
+                if (ci < G) { float *cr = con + CR_SIZE * ci; cr[CR_PAIR] = (float)p; cr[CR_ZONE] = (float)(m.pair_slot[p] + i); }   // ZONE slot reused for the source slot
+            }
+            base += tot;
+        }
+        ncon = base < G ? base : G;
+        if (ncon > m.nconmax) ncon = m.nconmax;
+    }
+    __syncthreads();
+    // E3 lane = contact: frame, impedance, regulariser, row addresses
+    {
+        int dim = 0;
+        float *cr = con + CR_SIZE * c;
+        int p = 0;
+        if (c < ncon) { p = (int)cr[CR_PAIR]; dim = m.pair_condim[p]; }
+        const int incl = gscan_incl<G>(dim, c);
+        const int adr = nlim + incl - dim;
+        const bool ovf = c < ncon && adr + dim > R;
+        // first overflowing contact truncates the list (njmax semantics)
+        unsigned long long bal = __ballot(ovf);
+        const unsigned int gm = (unsigned int)((bal >> (g * G)) & ((G == 32) ? 0xffffffffull : 0xffffull));
+        if (gm) ncon = __ffs(gm) - 1;
+        if (c < ncon) {
+            const int slot = (int)cr[CR_ZONE];
+            View cs{s.con + e, N};
+            const int b = slot * 7;
+            const v3 pos = mk3(cs[b], cs[b + 1], cs[b + 2]), nrm = mk3(cs[b + 3], cs[b + 4], cs[b + 5]);
+            const float dist = cs[b + 6];
+            v3 t1 = (nrm.y > -0.5f && nrm.y < 0.5f) ? mk3(0, 1, 0) : mk3(0, 0, 1);
+            t1 = normalized(t1 - nrm * dot(nrm, t1));
+            const v3 t2 = cross(nrm, t1);
+            const int g1 = m.pair_geom1[p], g2 = m.pair_geom2[p];
+            const float *solref = m.pair_solref + 2 * p, *solimp = m.pair_solimp + 5 * p, *fri = m.pair_friction + 5 * p;
+            const float imp = impedance(solimp, dist), dmax = fminf(fmaxf(solimp[1], HSR_MINIMP), HSR_MAXIMP);
+            const float tc = solref[0], dr = solref[1];
+            const float tran = m.geom_invweight[2 * g1] + m.geom_invweight[2 * g2];
+            const float B = 2.0f / (dmax * tc), Kimp = imp / (dmax * dmax * tc * tc * dr * dr);
+            const float R0 = fmaxf((1 - imp) / imp * tran, HSR_MINVAL), R1 = R0 / fmaxf(m.impratio, HSR_MINVAL);
+            cr[CR_POS] = pos.x; cr[CR_POS + 1] = pos.y; cr[CR_POS + 2] = pos.z;
+            cr[CR_N] = nrm.x; cr[CR_N + 1] = nrm.y; cr[CR_N + 2] = nrm.z;
+            cr[CR_T1] = t1.x; cr[CR_T1 + 1] = t1.y; cr[CR_T1 + 2] = t1.z;
+            cr[CR_T2] = t2.x; cr[CR_T2 + 1] = t2.y; cr[CR_T2 + 2] = t2.z;
+            cr[CR_DIST] = dist; cr[CR_MU] = dim > 1 ? fri[0] * sqrtf(R1 / R0) : fri[0];
+            cr[CR_ADR] = (float)adr; cr[CR_DIM] = (float)dim;
+            cr[CR_L1] = (float)m.geom_link[g1]; cr[CR_L2] = (float)m.geom_link[g2];
+            cr[CR_B] = B; cr[CR_KD] = Kimp * dist;
+            for (int j = 0; j < dim; j++) {
+                const float Rj = j == 0 ? R0 : (j == 1 ? R1 : R1 * fri[0] * fri[0] / (fri[j - 1] * fri[j - 1]));
+                rD[adr + j] = 1.0f / Rj;
+            }
+        }
+    }
+    __syncthreads();
+    // E4 lane = dof column: Jacobian entries of every contact row
+    int nefc = nlim;
+    for (int ci = 0; ci < ncon; ci++) {
+        const float *cr = con + CR_SIZE * ci;
+        const int adr = (int)cr[CR_ADR], dim = (int)cr[CR_DIM], l1 = (int)cr[CR_L1], l2 = (int)cr[CR_L2];
+        const int in1 = (m.link_dofmask[l1] >> c) & 1, in2 = (m.link_dofmask[l2] >> c) & 1;
+        const float sg = (float)(in2 - in1);
+        const v3 pos = mk3(cr[CR_POS], cr[CR_POS + 1], cr[CR_POS + 2]);
+        const v3 vp = (l_c + cross(a_c, pos - n_c)) * sg, wr = a_c * sg;
+        for (int j = 0; j < dim; j++) {
+            const int jj = j % 3;
+            const v3 ax = mk3(cr[3 + 3 * jj], cr[4 + 3 * jj], cr[5 + 3 * jj]);
+            J[(adr + j) * RS + c] = isdof ? dot(j < 3 ? vp : wr, ax) : 0.f;
+        }
+        nefc = adr + dim;
+    }
+    __syncthreads();
+    // E5 lane = row: reference acceleration of contact rows
+    for (int ci = c; ci < ncon; ci += G) {
+        const float *cr = con + CR_SIZE * ci;
+        const int adr = (int)cr[CR_ADR], dim = (int)cr[CR_DIM];
+        for (int j = 0; j < dim; j++) {
+            float vel = 0;
+            for (int k = 0; k < nv; k++) vel += J[(adr + j) * RS + k] * vQvel[k];
+            rAref[adr + j] = -cr[CR_B] * vel - (j == 0 ? cr[CR_KD] : 0.f);
+        }
+    }
+    __syncthreads();
+
+    // ---------------- phase F: Newton solver (a-2.6)
+    const float tol = m.tolerance, scale = 1.0f / (m.meaninertia * (nv > 1 ? nv : 1));
+    float cost = 0, Ma_c = 0;
+    // total cost at the acceleration stored in `va`; leaves Ma, jar, gr, dw and the cone records in LDS
+    auto eval_at = [&](const float *va) -> float {
+        float ma = 0;
+#pragma unroll
+        for (int k = 0; k < G; k++) ma += Mrow[k] * va[k];
+        Ma_c = isdof ? ma : 0.f;
+        float part = isdof ? 0.5f * (va[c] - qas_c) * (Ma_c - qfs_c) : 0.f;
+        for (int r = c; r < nefc; r += G) {
+            float sacc = -rAref[r];
+            for (int k = 0; k < nv; k++) sacc += J[r * RS + k] * va[k];
+            rJar[r] = sacc;
+            if (r < nlim) {
+                if (sacc < 0) { part += 0.5f * rD[r] * sacc * sacc; rGr[r] = rD[r] * sacc; rDw[r] = rD[r]; }
+                else { rGr[r] = 0; rDw[r] = 0; }
+            }
+        }
+        __syncthreads();
+        if (c < ncon) {
+            float *cr = con + CR_SIZE * c;
+            const int adr = (int)cr[CR_ADR], dim = (int)cr[CR_DIM], p = (int)cr[CR_PAIR];
+            float D[6], x[6], fri[5];
+#pragma unroll
+            for (int j = 0; j < 5; j++) fri[j] = m.pair_friction[5 * p + j];
+#pragma unroll
+            for (int j = 0; j < 6; j++) if (j < dim) { D[j] = rD[adr + j]; x[j] = rJar[adr + j]; } else { D[j] = 0; x[j] = 0; }
+            ConeOut o;
+            cone_eval2(dim, cr[CR_MU], fri, D, x, o);
+            part += o.cost;
+            cr[CR_ZONE] = (float)o.zone; cr[CR_DM] = o.Dm; cr[CR_K3] = o.k3;
+#pragma unroll
+            for (int j = 0; j < 6; j++) { cr[CR_GN + j] = o.gn[j]; cr[CR_U + j] = o.u[j]; if (j < dim) { rGr[adr + j] = o.g[j]; rDw[adr + j] = o.dw[j]; } }
+        }
+        const float tot = gsum<G>(part);
+        __syncthreads();
+        return tot;
+    };
+
+    bool active = valid && nefc > 0;
+    int iter = 0;
+    {
+        const float cost_s = eval_at(vQas);
+        const float cost_w = eval_at(vWarm);
+        // block-uniform control flow: if any group prefers qacc_smooth, everyone re-evaluates at its own start
+        const bool use_warm = cost_w < cost_s;
+        vQacc[c] = use_warm ? vWarm[c] : vQas[c];
+        cost = use_warm ? cost_w : cost_s;
+        if (__syncthreads_or(!use_warm)) cost = eval_at(vQacc);
+        __syncthreads();
+    }
+    for (int it = 0; it < m.iterations; it++) {
+        if (!__syncthreads_or(active)) break;
+        // gradient, lane = dof
+        float grad_c = 0;
+        if (isdof) {
+            grad_c = Ma_c - qfs_c;
+            for (int r = 0; r < nefc; r++) grad_c += J[r * RS + c] * rGr[r];
+        }
+        const float gnorm = sqrtf(gsum<G>(grad_c * grad_c));
+        if (scale * gnorm < tol) active = false;
+        // Hessian rows H = M + J^T (d2s) J, lane = row c of H
+        float Hrow[G];
+#pragma unroll
+        for (int k = 0; k < G; k++) Hrow[k] = Mrow[k];
+        if (active) {
+            for (int r = 0; r < nefc; r++) {
+                const float w = rDw[r];
+                if (w != 0.f) {
+                    const float t = w * J[r * RS + c];
+                    const float4 *jr = reinterpret_cast<const float4 *>(J + r * RS);
+#pragma unroll
+                    for (int k4 = 0; k4 < G / 4; k4++) {
+                        const float4 q = jr[k4];
+                        Hrow[4 * k4] += t * q.x; Hrow[4 * k4 + 1] += t * q.y; Hrow[4 * k4 + 2] += t * q.z; Hrow[4 * k4 + 3] += t * q.w;
+                    }
+                }
+            }
+            for (int ci = 0; ci < ncon; ci++) {
+                const float *cr = con + CR_SIZE * ci;
+                if ((int)cr[CR_ZONE] != 2) continue;
+                const int adr = (int)cr[CR_ADR], dim = (int)cr[CR_DIM];
+                float pc = 0, wc = 0;
+                for (int j = 0; j < dim; j++) { const float jc = J[(adr + j) * RS + c]; pc += jc * cr[CR_GN + j]; wc += jc * cr[CR_U + j]; }
+                const float Dm = cr[CR_DM], k3 = cr[CR_K3];
+#pragma unroll
+                for (int k = 0; k < G; k++) {
+                    const float pk = __shfl(pc, k, G), wk = __shfl(wc, k, G);
+                    Hrow[k] += Dm * pc * pk - k3 * wc * wk;
+                }
+            }
+        }
+        if (!isdof) {
+#pragma unroll
+            for (int k = 0; k < G; k++) Hrow[k] = (k == c) ? 1.f : 0.f;
+        }
+        if (!chol_g<G>(Hrow, nv, c) && active) { bad = 1; active = false; }
+        float search_c = chol_solve_g<G>(Hrow, -grad_c, nv, c, tile);
+        if (!isdof) search_c = 0;
+        __syncthreads();
+        vSearch[c] = search_c;
+        __syncthreads();
+        // exact line search (safeguarded 1-D Newton on phi'), all reductions by shuffles
+        float mv = 0;
+#pragma unroll
+        for (int k = 0; k < G; k++) mv += Mrow[k] * vSearch[k];
+        const float g1 = gsum<G>(search_c * (Ma_c - qfs_c)), g2 = gsum<G>(isdof ? search_c * mv : 0.f), snorm = sqrtf(gsum<G>(search_c * search_c));
+        for (int r = c; r < nefc; r += G) {
+            float sacc = 0;
+            for (int k = 0; k < nv; k++) sacc += J[r * RS + k] * vSearch[k];
+            rJv[r] = sacc;
+        }
+        __syncthreads();
+        float alpha = 0;
+        if (active) {
+            // per-lane constants of the 1-D function
+            float cD[6], cx[6], cv[6], cfri[5], cmu = 0;
+            int cdim = 0;
+            if (c < ncon) {
+                const float *cr = con + CR_SIZE * c;
+                const int adr = (int)cr[CR_ADR], p = (int)cr[CR_PAIR];
+                cdim = (int)cr[CR_DIM]; cmu = cr[CR_MU];
+#pragma unroll
+                for (int j = 0; j < 5; j++) cfri[j] = m.pair_friction[5 * p + j];
+#pragma unroll
+                for (int j = 0; j < 6; j++) if (j < cdim) { cD[j] = rD[adr + j]; cx[j] = rJar[adr + j]; cv[j] = rJv[adr + j]; } else { cD[j] = 0; cx[j] = 0; cv[j] = 0; }
+            }
+            auto ls_eval = [&](float al, float &dphi, float &ddphi) {
+                float dp = 0, hp = 0;
+                for (int r = c; r < nlim; r += G) {
+                    const float jvi = rJv[r], x = rJar[r] + al * jvi;
+                    if (x < 0) { dp += rD[r] * x * jvi; hp += rD[r] * jvi * jvi; }
+                }
+                if (c < ncon) {
+                    float x[6];
+#pragma unroll
+                    for (int j = 0; j < 6; j++) x[j] = cx[j] + al * cv[j];
+                    ConeOut o;
+                    cone_eval2(cdim, cmu, cfri, cD, x, o);
+                    float gv = 0, gnv = 0, uv = 0, dwv = 0;
+#pragma unroll
+                    for (int j = 0; j < 6; j++) { gv += o.g[j] * cv[j]; gnv += o.gn[j] * cv[j]; uv += o.u[j] * cv[j]; dwv += o.dw[j] * cv[j] * cv[j]; }
+                    dp += gv; hp += dwv + o.Dm * gnv * gnv - o.k3 * uv * uv;
+                }
+                dphi = g1 + al * g2 + gsum<G>(dp);
+                ddphi = g2 + gsum<G>(hp);
+            };
+            const float gtol = tol * m.ls_tolerance * snorm / scale;
+            float dp, hp, lo = 0, hi = -1;
+            ls_eval(0.f, dp, hp);
+            // fp32 termination: the Newton decrement -dp/2 predicts the cost decrease without the
+            // cancellation of (cost - newcost) between two large fp32 costs
+            if (dp >= 0 || hp <= 0 || scale * 0.5f * (-dp) < tol) active = false;
+            else {
+                alpha = -dp / hp;
+                for (int k = 0; k < m.ls_iterations; k++) {
+                    ls_eval(alpha, dp, hp);
+                    if (fabsf(dp) < gtol) break;
+                    if (dp < 0) lo = alpha; else hi = alpha;
+                    float nxt = alpha - dp / hp;
+                    if (!(nxt > lo) || (hi > 0 && !(nxt < hi))) nxt = hi > 0 ? 0.5f * (lo + hi) : 2 * alpha;
+                    if (nxt == alpha) break;
+                    alpha = nxt;
+                }
+                if (!(alpha > 0)) { active = false; alpha = 0; }
+            }
+        }
+        if (active) vQacc[c] += alpha * search_c;
+        __syncthreads();
+        const float newcost = eval_at(vQacc);
+        if (active) { iter++; cost = newcost; }
+    }
+    float qacc_c = vQacc[c], qfc_c = 0;
+    if (nefc == 0) qacc_c = qas_c;
+    else if (isdof) for (int r = 0; r < nefc; r++) qfc_c -= J[r * RS + c] * rGr[r];
+    if (valid && isdof) {
+        s.qacc[(size_t)c * N + e] = qacc_c;
+        if (debug) { s.qacc_smooth[(size_t)c * N + e] = qas_c; s.qfrc_smooth[(size_t)c * N + e] = qfs_c; s.qfrc_constraint[(size_t)c * N + e] = qfc_c; }
+    }
+    if (valid && c == 0) { s.ncon[e] = ncon; s.nefc[e] = nefc; s.niter[e] = iter; }
+    if (mode == 0) {
+        const float bsum = gsum<G>((float)bad);
+        if (valid && c == 0 && bsum > 0) s.bad[e] = 1;
+        return;
+    }
+
+    // ---------------- phase G: mj_Euler (a-2.7): implicit joint damping, semi-implicit update
+    const float h = m.timestep;
+    float acc_c = qacc_c;
+    if (m.any_damping) {
+        float Ar[G];
+#pragma unroll
+        for (int k = 0; k < G; k++) Ar[k] = Mrow[k] + ((k == c) ? h * damp_c : 0.f);
+        if (!chol_g<G>(Ar, nv, c)) bad = 1;
+        acc_c = chol_solve_g<G>(Ar, qfs_c + qfc_c, nv, c, tile);
+    }
+    const float vnew = qvel_c + h * acc_c;
+    if (!(fabsf(vnew) <= 1e10f) && isdof) bad = 1;
+    __syncthreads();
+    vSearch[c] = isdof ? vnew : 0.f;
+    __syncthreads();
+    if (valid && isdof) {
+        s.qvel[(size_t)c * N + e] = vnew;
+        s.warm[(size_t)c * N + e] = qacc_c;
+        const int t = m.dof_type[c];
+        const int adr = m.dof_qposadr[c];
+        if (t == DOF_SLIDE || t == DOF_HINGE || t == DOF_FREE_LIN) s.qpos[(size_t)adr * N + e] += h * vnew;
+        else if (c == m.link_dofadr[m.dof_link[c]] + 3) {
+            // first rotational dof of a free joint integrates the quaternion (mju_quatIntegrate)
+            const v3 w = mk3(vSearch[c], vSearch[c + 1], vSearch[c + 2]);
+            const float wn = norm(w), angle = wn * h;
+            if (angle > 0) {
+                const v3 ax = w * (1.0f / wn);
+                float sn, cs;
+                sincosf(0.5f * angle, &sn, &cs);
+                q4 q, qr;
+                q.w = s.qpos[(size_t)adr * N + e]; q.x = s.qpos[(size_t)(adr + 1) * N + e]; q.y = s.qpos[(size_t)(adr + 2) * N + e]; q.z = s.qpos[(size_t)(adr + 3) * N + e];
+                qr.w = cs; qr.x = ax.x * sn; qr.y = ax.y * sn; qr.z = ax.z * sn;
+                q = qnormalized(qmul(q, qr));
+                s.qpos[(size_t)adr * N + e] = q.w; s.qpos[(size_t)(adr + 1) * N + e] = q.x; s.qpos[(size_t)(adr + 2) * N + e] = q.y; s.qpos[(size_t)(adr + 3) * N + e] = q.z;
+            }
+        }
+    }
+    const float bsum = gsum<G>((float)bad);
+    if (valid && c == 0) {
+        s.time[e] += h;
+        s.nsteps[e] += 1;
+        if (bsum > 0) s.bad[e] = 1;
+        // a-3 / a-4 goal test on the xpos of this substep's forward pass, latch done
+        if (goal_body >= 0) {
+            v3 bp;
+            const v3 goal = mk3(s.mocap[e], s.mocap[N + e], s.mocap[2 * N + e]);
+            if (m.body_mocap[goal_body]) bp = goal;
+            else {
+                const int l = m.body_link[goal_body];
+                View xpos{s.xpos + e, N}, xmat{s.xmat + e, N};
+                bp = xpos.get3(l) + mulmv(xmat.getm(l), ld3(m.body_pos, goal_body));
+            }
+            if (norm(bp - goal) < geofence) s.done[e] = 1;
+        }
+    }
+}
