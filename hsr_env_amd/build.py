@@ -10,16 +10,20 @@ OUT = HERE / "libhsrsim.so"
 HIPCC = "/opt/rocm/bin/hipcc"
 
 
-def build_lib(force: bool = False, verbose: bool = False) -> Path:
+def build_lib(force: bool = False, verbose: bool = False, timing: bool = False) -> Path:
+    """timing=True builds the diagnostic variant libhsrsim_timing.so (in-kernel phase stamps; never benchmarked)."""
+    out = HERE / "libhsrsim_timing.so" if timing else OUT
     deps = list((HERE / "csrc").glob("*")) + [HERE.parent / "include" / "hsrsim.h"]
-    if not force and OUT.exists() and all(OUT.stat().st_mtime >= d.stat().st_mtime for d in deps):
-        return OUT
+    if not force and out.exists() and all(out.stat().st_mtime >= d.stat().st_mtime for d in deps):
+        return out
     cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-result", "-Wno-unused-value",
-           "-o", str(OUT), str(SRC)]
+           "-o", str(out), str(SRC)]
+    if timing:
+        cmd.append("-DHSR_PHASE_TIMING")
     if verbose:
         cmd.append("-Rpass-analysis=kernel-resource-usage")
     subprocess.check_call(cmd)
-    return OUT
+    return out
 
 
 if __name__ == "__main__":

@@ -137,7 +137,7 @@ struct Geom {
     int type, nvert;
     v3 pos, size;
     m3 mat;
-    const float *verts;
+    const float4 *verts;      // hull vertices staged in LDS (xyz, w unused); all lanes of the wave share the mesh
 };
 
 __device__ __forceinline__ Geom load_geom(const DevModel &m, const DevState &s, int g, int e) {
@@ -149,7 +149,7 @@ __device__ __forceinline__ Geom load_geom(const DevModel &m, const DevState &s, 
     G.mat = mulmm(R, ldm(m.geom_mat, g));
     G.type = m.geom_type[g];
     G.size = ld3(m.geom_size, g);
-    G.verts = m.mesh_vert + 3 * m.geom_meshadr[g];
+    G.verts = nullptr;
     G.nvert = m.geom_meshnum[g];
     return G;
 }
@@ -167,26 +167,36 @@ __device__ __forceinline__ v3 support(const Geom &G, v3 dir) {
     } else if (G.type == GEOM_SPHERE) {
         loc = normalized(dl) * G.size.x;
     } else {
-        // mesh hull: vertex table is wave-uniform (pair index = blockIdx.y) -> scalar loads
+        // mesh hull: exhaustive search, first maximum wins; vertices are LDS broadcast reads, 4 in flight
         float bd = -3.0e38f;
         loc = mk3(0, 0, 0);
-        for (int i = 0; i < G.nvert; i++) {
-            const v3 v = ld3(G.verts, i);
-            const float t = dot(v, dl);
-            if (t > bd) { bd = t; loc = v; }
+        int i = 0;
+        for (; i + 4 <= G.nvert; i += 4) {
+            const float4 a = G.verts[i], b = G.verts[i + 1], c4 = G.verts[i + 2], d = G.verts[i + 3];
+            const float ta = a.x * dl.x + a.y * dl.y + a.z * dl.z, tb = b.x * dl.x + b.y * dl.y + b.z * dl.z;
+            const float tc = c4.x * dl.x + c4.y * dl.y + c4.z * dl.z, td = d.x * dl.x + d.y * dl.y + d.z * dl.z;
+            if (ta > bd) { bd = ta; loc = mk3(a.x, a.y, a.z); }
+            if (tb > bd) { bd = tb; loc = mk3(b.x, b.y, b.z); }
+            if (tc > bd) { bd = tc; loc = mk3(c4.x, c4.y, c4.z); }
+            if (td > bd) { bd = td; loc = mk3(d.x, d.y, d.z); }
+        }
+        for (; i < G.nvert; i++) {
+            const float4 a = G.verts[i];
+            const float t = a.x * dl.x + a.y * dl.y + a.z * dl.z;
+            if (t > bd) { bd = t; loc = mk3(a.x, a.y, a.z); }
         }
     }
     return mulmv(G.mat, loc) + G.pos;
 }
 
 struct ContactOut {
-    View con;      // slot-major contact records of this env
+    float *con;    // contact records of this env: [slot][8]
     int slot, cnt, maxcnt;
     __device__ __forceinline__ void add(v3 pos, v3 n, float dist) {
         if (cnt >= maxcnt) return;
-        const int b = (slot + cnt) * 7;
-        con[b] = pos.x; con[b + 1] = pos.y; con[b + 2] = pos.z;
-        con[b + 3] = n.x; con[b + 4] = n.y; con[b + 5] = n.z; con[b + 6] = dist;
+        float4 *r = reinterpret_cast<float4 *>(con + (size_t)(slot + cnt) * 8);
+        r[0] = make_float4(pos.x, pos.y, pos.z, n.x);
+        r[1] = make_float4(n.y, n.z, dist, 0.f);
         cnt++;
     }
 };
@@ -463,36 +473,79 @@ __device__ bool mpr_penetration(const Geom &G1, const Geom &G2, float tol, int m
     }
 }
 
+// half extents of a box that contains the geom in its own frame
+__device__ __forceinline__ v3 obb_half(const Geom &G) {
+    if (G.type == GEOM_CYLINDER) return mk3(G.size.x, G.size.x, G.size.y);
+    if (G.type == GEOM_SPHERE) return mk3(G.size.x, G.size.x, G.size.x);
+    return G.size;            // box half sizes; mesh: max |vertex coordinate| per axis (compiler.py)
+}
+__device__ __forceinline__ bool sphere_hits_obb(v3 c, float r, const Geom &B) {
+    const v3 l = mulmtv(B.mat, c - B.pos), h = obb_half(B);
+    const float dx = fmaxf(fabsf(l.x) - h.x, 0.f), dy = fmaxf(fabsf(l.y) - h.y, 0.f), dz = fmaxf(fabsf(l.z) - h.z, 0.f);
+    return dx * dx + dy * dy + dz * dz <= r * r;
+}
+
 // one wave per (64 envs, candidate pair): pair index blockIdx.y is wave-uniform, so the narrowphase
 // function, geom constants and mesh vertex tables are scalar data; lanes differ only in env state.
+#define MAXMESHV 256
 __global__ void __launch_bounds__(64) k_collide(DevModel m, DevState s) {
     __shared__ float poly[2 * 8 * 3 * 64];
+    __shared__ float4 vbuf[2][MAXMESHV];
     const int lane = threadIdx.x;
     const int e = blockIdx.x * 64 + lane;
-    const int p = blockIdx.y;
-    if (e >= s.N) return;
-    if (s.done[e]) return;
-    const int N = s.N;
-    const int g1 = m.pair_geom1[p], g2 = m.pair_geom2[p];
-    const Geom G1 = load_geom(m, s, g1, e), G2 = load_geom(m, s, g2, e);
-    ContactOut out;
-    out.con = View{s.con + e, N};
-    out.slot = m.pair_slot[p];
-    out.maxcnt = m.pair_slot[p + 1] - m.pair_slot[p];
-    out.cnt = 0;
-    // mj_collideGeoms bounding test (margin 0)
-    bool pass;
-    if (G1.type == GEOM_PLANE) pass = dot(G2.pos - G1.pos, col(G1.mat, 2)) <= m.geom_rbound[g2];
-    else { const v3 r = G2.pos - G1.pos; const float b = m.geom_rbound[g1] + m.geom_rbound[g2]; pass = dot(r, r) <= b * b; }
-    if (pass) {
-        const int fn = m.pair_fn[p];
-        if (fn == FN_PLANE_BOX) collide_plane_box(G1, G2, out);
-        else if (fn == FN_PLANE_CONVEX) collide_plane_convex(G1, G2, out);
-        else if (fn == FN_BOX_BOX) collide_box_box(G1, G2, out, poly, lane);
-        else {
-            float depth; v3 dir, pos;
-            if (mpr_penetration(G1, G2, m.mpr_tolerance, m.mpr_iterations, depth, dir, pos)) out.add(pos, dir, -depth);
+    const bool live = e < s.N && !s.done[e < s.N ? e : 0];
+    if (!__any(live)) return;
+    const int es = live ? e : 0;
+    // one wave walks several candidate pairs; the pair index is wave-uniform, so the narrowphase function,
+    // geom constants and mesh tables are shared by all 64 envs of the wave
+    for (int pv = blockIdx.y; pv < m.npair; pv += gridDim.y) {
+        const int p = __builtin_amdgcn_readfirstlane(pv);
+        const int g1 = m.pair_geom1[p], g2 = m.pair_geom2[p];
+        Geom G1 = load_geom(m, s, g1, es), G2 = load_geom(m, s, g2, es);
+        ContactOut out;
+        out.con = s.con + (size_t)es * m.nslot * 8;
+        out.slot = m.pair_slot[p];
+        out.maxcnt = m.pair_slot[p + 1] - m.pair_slot[p];
+        out.cnt = 0;
+        // mj_collideGeoms bounding-sphere test (margin 0), then a tighter conservative cull: bounding sphere of one
+        // geom against the oriented bounding box of the other.  A contact needs the geoms to intersect, which
+        // implies every one of these tests passes, so the contact set is unchanged; the cull only spares the
+        // narrowphase (MPR over hull vertices) for pairs such as thin pan plate vs robot links.
+        bool pass;
+        if (G1.type == GEOM_PLANE) {
+            const v3 n = col(G1.mat, 2);
+            const float dc = dot(G2.pos - G1.pos, n);
+            pass = dc <= m.geom_rbound[g2];
+            if (pass) {
+                const v3 h = obb_half(G2);
+                pass = dc - (fabsf(dot(n, col(G2.mat, 0))) * h.x + fabsf(dot(n, col(G2.mat, 1))) * h.y + fabsf(dot(n, col(G2.mat, 2))) * h.z) <= 0.f;
+            }
+        } else {
+            const v3 r = G2.pos - G1.pos;
+            const float r1 = m.geom_rbound[g1], r2 = m.geom_rbound[g2], b = r1 + r2;
+            pass = dot(r, r) <= b * b;
+            if (pass) pass = sphere_hits_obb(G2.pos, r2, G1) && sphere_hits_obb(G1.pos, r1, G2);
         }
+        pass = pass && live;
+        if (__any(pass)) {
+            const int fn = m.pair_fn[p];
+            if (fn == FN_PLANE_CONVEX || fn == FN_CONVEX) {
+                // stage the hull vertices of the mesh geoms in LDS (cooperative copy, one wave)
+                __syncthreads();
+                if (G1.type == GEOM_MESH) { const float4 *src = m.mesh_vert4 + m.geom_meshadr[g1]; for (int i = lane; i < G1.nvert; i += 64) vbuf[0][i] = src[i]; G1.verts = vbuf[0]; }
+                if (G2.type == GEOM_MESH) { const float4 *src = m.mesh_vert4 + m.geom_meshadr[g2]; for (int i = lane; i < G2.nvert; i += 64) vbuf[1][i] = src[i]; G2.verts = vbuf[1]; }
+                __syncthreads();
+            }
+            if (pass) {
+                if (fn == FN_PLANE_BOX) collide_plane_box(G1, G2, out);
+                else if (fn == FN_PLANE_CONVEX) collide_plane_convex(G1, G2, out);
+                else if (fn == FN_BOX_BOX) collide_box_box(G1, G2, out, poly, lane);
+                else {
+                    float depth; v3 dir, pos;
+                    if (mpr_penetration(G1, G2, m.mpr_tolerance, m.mpr_iterations, depth, dir, pos)) out.add(pos, dir, -depth);
+                }
+            }
+        }
+        if (live) s.ncon_pair[(size_t)e * m.npair_pad + p] = out.cnt;
     }
-    s.ncon_pair[(size_t)p * N + e] = out.cnt;
 }

@@ -161,6 +161,7 @@ struct hsr_batch {
     int32_t *d_stage_i32 = nullptr;
     int hot_threads = 64;
     size_t hot_lds_bytes = 0;
+    int pairs_per_wave = 4;        // k_collide: pairs walked by one wave (HSR_PPW overrides)
     int solver = 1;                // 0: one lane per env (solve.h), 1: lane group per env (solve_g.h)
     int group = 16;
     size_t group_lds_bytes = 0;
@@ -293,11 +294,11 @@ __global__ void k_contacts_out(DevModel m, DevState s, float *out) {   // [N, ns
     if (e >= s.N) return;
     const int N = s.N;
     for (int p = 0; p < m.npair; p++) {
-        const int cnt = s.ncon_pair[(size_t)p * N + e];
+        const int cnt = s.ncon_pair[(size_t)e * m.npair_pad + p];
         for (int slot = m.pair_slot[p]; slot < m.pair_slot[p + 1]; slot++) {
             float *o = out + ((size_t)e * m.nslot + slot) * 7;
             const bool used = slot - m.pair_slot[p] < cnt;
-            for (int k = 0; k < 7; k++) o[k] = used ? s.con[(size_t)(slot * 7 + k) * N + e] : (k == 6 ? 1.f : 0.f);
+            for (int k = 0; k < 7; k++) o[k] = used ? s.con[((size_t)e * m.nslot + slot) * 8 + k] : (k == 6 ? 1.f : 0.f);
         }
     }
 }
@@ -344,6 +345,40 @@ extern "C" int hsr_batch_create(const hsr_model *m, int n_envs, int device_id, h
     UI(act_dof) UF(act_gear) UF(act_kp) UF(act_ctrlrange) UF(act_forcerange)
 #undef UI
 #undef UF
+    {   // hull vertices as float4
+        size_t cnt = 0;
+        const double *mv = m->f64("mesh_vert", &cnt);
+        const size_t nvt = cnt / 3;
+        std::vector<float> v4((nvt + 1) * 4, 0.f);
+        for (size_t i = 0; i < nvt; i++) for (int k = 0; k < 3; k++) v4[4 * i + k] = (float)mv[3 * i + k];
+        float *dv; if ((rc = dalloc(b, &dv, v4.size()))) return rc;
+        HIPCHK(hipMemcpy(dv, v4.data(), v4.size() * sizeof(float), hipMemcpyHostToDevice));
+        d.mesh_vert4 = reinterpret_cast<const float4 *>(dv);
+        const int *mn = m->i32("geom_meshnum");
+        for (int g = 0; g < d.ngeom; g++) if (mn[g] > 256) return fail(HSR_EINVAL, "mesh hull with more than 256 vertices");
+    }
+    d.npair_pad = (d.npair + 31) & ~31;
+    if (d.npair_pad == 0) d.npair_pad = 32;
+    {   // derived tables: per-pair record and dof -> actuator map
+        const int *g1 = m->i32("pair_geom1"), *g2 = m->i32("pair_geom2"), *cd = m->i32("pair_condim"), *gl = m->i32("geom_link"), *ad = m->i32("act_dof");
+        const double *fr = m->f64("pair_friction"), *sr = m->f64("pair_solref"), *si = m->f64("pair_solimp"), *iw = m->f64("geom_invweight");
+        std::vector<float> rec((size_t)std::max(d.npair, 1) * 16, 0.f);
+        for (int p = 0; p < d.npair; p++) {
+            float *r = rec.data() + 16 * p;
+            r[0] = (float)cd[p]; r[1] = (float)gl[g1[p]]; r[2] = (float)gl[g2[p]]; r[3] = (float)(iw[2 * g1[p]] + iw[2 * g2[p]]);
+            for (int j = 0; j < 5; j++) r[4 + j] = (float)fr[5 * p + j];
+            r[9] = (float)sr[2 * p]; r[10] = (float)sr[2 * p + 1];
+            for (int j = 0; j < 5; j++) r[11 + j] = (float)si[5 * p + j];
+        }
+        float *drec; if ((rc = dalloc(b, &drec, rec.size()))) return rc;
+        HIPCHK(hipMemcpy(drec, rec.data(), rec.size() * sizeof(float), hipMemcpyHostToDevice));
+        d.pair_rec = drec;
+        std::vector<int> da(std::max(d.nv, 1), -1);
+        for (int a = 0; a < d.nu; a++) da[ad[a]] = a;
+        int *dda; if ((rc = dalloc(b, &dda, da.size()))) return rc;
+        HIPCHK(hipMemcpy(dda, da.data(), da.size() * sizeof(int), hipMemcpyHostToDevice));
+        d.dof_act = dda;
+    }
     if ((rc = upload_mats(b, &d.link_mat, m, "link_quat"))) return rc;
     if ((rc = upload_mats(b, &d.geom_mat, m, "geom_quat"))) return rc;
     d.any_damping = 0;
@@ -356,7 +391,7 @@ extern "C" int hsr_batch_create(const hsr_model *m, int n_envs, int device_id, h
     DA(qpos, d.nq) DA(qvel, d.nv) DA(ctrl, d.nu) DA(mocap, 3) DA(warm, d.nv) DA(time, 1)
     DA(done, 1) DA(bad, 1) DA(nsteps, 1)
     DA(xpos, 3 * d.nlink) DA(xmat, 9 * d.nlink) DA(dof_ang, 3 * d.nv) DA(dof_lin, 3 * d.nv) DA(dof_anchor, 3 * d.nv) DA(link_dyn, 15 * d.nlink)
-    DA(con, 7 * d.nslot) DA(ncon_pair, d.npair)
+    DA(con, 8 * d.nslot) DA(ncon_pair, d.npair_pad)
     DA(M, d.nM) DA(qacc, d.nv) DA(qacc_smooth, d.nv) DA(qfrc_smooth, d.nv) DA(qfrc_constraint, d.nv)
     DA(ncon, 1) DA(nefc, 1) DA(niter, 1)
     // solver workspace rows
@@ -371,6 +406,7 @@ extern "C" int hsr_batch_create(const hsr_model *m, int n_envs, int device_id, h
     s.ws_floats = o;
     DA(ws, o)
 #undef DA
+    if ((rc = dalloc(b, &s.phase_cyc, 32))) return rc;
     b->hot_threads = 64;
     b->hot_lds_bytes = (size_t)s.hot_floats * 64 * sizeof(float);
     s.hot_in_lds = b->hot_lds_bytes <= 150 * 1024 ? 1 : 0;
@@ -380,10 +416,13 @@ extern "C" int hsr_batch_create(const hsr_model *m, int n_envs, int device_id, h
     // cooperative solver geometry: 16 lanes per env when nv <= 16, else 32
     b->group = d.nv <= 16 ? 16 : 32;
     {
+        const char *ppw = getenv("HSR_PPW");
+        if (ppw && atoi(ppw) > 0) b->pairs_per_wave = atoi(ppw);
         const char *sv = getenv("HSR_SOLVER");
         b->solver = (sv && strcmp(sv, "v1") == 0) ? 0 : 1;
         if (d.nv > 32 || d.nlink > NLMAX || d.nconmax > b->group) b->solver = 0;
         const int total = b->group == 16 ? SolveLayout<16>(d.njmax).total : SolveLayout<32>(d.njmax).total;
+        if (!(b->group == 16 ? SolveLayout<16>(d.njmax).fits() : SolveLayout<32>(d.njmax).fits())) b->solver = 0;
         b->group_lds_bytes = (size_t)total * (64 / b->group) * sizeof(float);
         if (b->group_lds_bytes > 160 * 1024) b->solver = 0;
         if (b->solver && b->group_lds_bytes > 48 * 1024) {
@@ -433,7 +472,7 @@ static void launch_substep(hsr_batch *b, int mode, int goal_body, float geofence
     rec();
     hipLaunchKernelGGL(k_kinematics, dim3((N + 63) / 64), dim3(64), 0, st, b->dm, b->ds);
     rec();
-    if (b->dm.npair > 0) hipLaunchKernelGGL(k_collide, dim3((N + 63) / 64, b->dm.npair), dim3(64), 0, st, b->dm, b->ds);
+    if (b->dm.npair > 0) hipLaunchKernelGGL(k_collide, dim3((N + 63) / 64, (b->dm.npair + b->pairs_per_wave - 1) / b->pairs_per_wave), dim3(64), 0, st, b->dm, b->ds);
     rec();
     if (b->solver == 0) hipLaunchKernelGGL(k_solve, dim3((N + 63) / 64), dim3(64), b->hot_lds_bytes, st, b->dm, b->ds, mode, goal_body, geofence, debug);
     else if (b->group == 16) hipLaunchKernelGGL(k_solve_g<16>, dim3((N + 3) / 4), dim3(64), b->group_lds_bytes, st, b->dm, b->ds, mode, goal_body, geofence, debug);
@@ -639,6 +678,15 @@ extern "C" int hsr_batch_get_field(hsr_batch *b, int field, float *out) {
         return HSR_OK;
     default: return fail(HSR_EINVAL, "unknown field");
     }
+}
+
+// diagnostic builds (-DHSR_PHASE_TIMING): read and clear the per-phase cycle sums of k_solve_g
+extern "C" int hsr_batch_phase_cycles(hsr_batch *b, unsigned long long *out /*[32]*/) {
+    HIPCHK(hipSetDevice(b->device));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    HIPCHK(hipMemcpy(out, b->ds.phase_cyc, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemset(b->ds.phase_cyc, 0, 32 * sizeof(unsigned long long)));
+    return HSR_OK;
 }
 
 extern "C" int hsr_batch_last_timing(hsr_batch *b, float *total_ms, float *kernel_ms, int *launches) {

@@ -1,6 +1,7 @@
 // Device-side model tables and per-batch state (struct-of-arrays, [field][env]).
 #pragma once
 #include <stdint.h>
+#include <hip/hip_runtime.h>
 
 enum { DOF_SLIDE = 0, DOF_HINGE = 1, DOF_FREE_LIN = 2, DOF_FREE_ANG = 3 };
 enum { GEOM_PLANE = 0, GEOM_SPHERE = 2, GEOM_CYLINDER = 5, GEOM_BOX = 6, GEOM_MESH = 7 };
@@ -20,9 +21,12 @@ struct DevModel {
     const float *body_pos;
     const int *geom_type, *geom_link, *geom_meshadr, *geom_meshnum;
     const float *geom_pos, *geom_mat, *geom_size, *geom_rbound, *geom_invweight, *mesh_vert;
+    const float4 *mesh_vert4;          // hull vertices padded to float4 (LDS staging in k_collide)
     const int *pair_geom1, *pair_geom2, *pair_fn, *pair_condim, *pair_slot;
     const float *pair_friction, *pair_solref, *pair_solimp;
-    const int *act_dof;
+    const int *act_dof, *dof_act;     // dof_act[k]: actuator driving dof k or -1
+    const float *pair_rec;            // [npair][16]: dim l1 l2 tran fri[5] solref[2] solimp[5]
+    int npair_pad;                    // npair rounded up to 32: row length of the per-env pair-count table
     const float *act_gear, *act_kp, *act_ctrlrange, *act_forcerange;
 };
 
@@ -36,7 +40,8 @@ struct DevState {
     float *xpos, *xmat, *dof_ang, *dof_lin, *dof_anchor;
     // per-link dynamics terms from the kinematics kernel: com(3) Iworld(6: xx yy zz xy xz yz) F(3) N(3)
     float *link_dyn;
-    // collision outputs: contact slots (7 floats: pos, normal, dist) and per-pair counts
+    // collision outputs, env-major so that one env's lane group reads them coalesced:
+    //   con[(e * nslot + slot) * 8 + k]  (pos 0-2, normal 3-5, dist 6), ncon_pair[e * npair_pad + p]
     float *con;
     int *ncon_pair;
     // dynamics / solver outputs kept for introspection
@@ -49,4 +54,5 @@ struct DevState {
     int o_lw, o_lvo, o_lal, o_lao, o_J, o_D, o_aref, o_jar, o_jv, o_gr, o_cpair, o_cmu, o_T, o_hot;
     int hot_floats;      // rows of the "hot" per-thread block (M, H, vectors); lives in LDS when it fits
     int hot_in_lds;
+    unsigned long long *phase_cyc;   // diagnostic build only (HSR_PHASE_TIMING): per-phase cycle sums
 };

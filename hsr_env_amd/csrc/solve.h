@@ -336,13 +336,13 @@ __global__ void __launch_bounds__(64) k_solve(DevModel m, DevState s, int mode, 
     c.nlim = ne;
     int ncon = 0;
     {
-        View con{s.con + e, N};
+        const float *con = s.con + (size_t)e * m.nslot * 8;
         for (int p = 0; p < m.npair; p++) {
-            const int cnt = s.ncon_pair[(size_t)p * N + e];
+            const int cnt = s.ncon_pair[(size_t)e * m.npair_pad + p];
             for (int i = 0; i < cnt; i++) {
                 const int dim = m.pair_condim[p];
                 if (ncon >= m.nconmax || ne + dim > m.njmax) break;
-                const int b = (m.pair_slot[p] + i) * 7;
+                const int b = (m.pair_slot[p] + i) * 8;
                 const v3 pos = mk3(con[b], con[b + 1], con[b + 2]), nrm = mk3(con[b + 3], con[b + 4], con[b + 5]);
                 const float dist = con[b + 6];
                 // mju_makeFrame

@@ -13,50 +13,87 @@
 #include "devmath.h"
 #include "model.h"
 #include "solve.h"
+#include <type_traits>
 
+#ifdef HSR_PHASE_TIMING
+#define PHASE_T0() unsigned long long t_prev_ = __builtin_amdgcn_s_memtime(); int ph_ = 0
+#define PHASE(idx) do { unsigned long long t_now_ = __builtin_amdgcn_s_memtime(); if (tid == 0) atomicAdd(&s.phase_cyc[idx], t_now_ - t_prev_); t_prev_ = __builtin_amdgcn_s_memtime(); (void)ph_; } while (0)
+#else
+#define PHASE_T0() do {} while (0)
+#define PHASE(idx) do {} while (0)
+#endif
+template <int I, int N, typename F> __device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
+}
+// DPP controls (gfx90a+): row_shr:n = 0x110+n, row_ror:n = 0x120+n, row_newbcast:n = 0x150+n; a "row" is 16 lanes,
+// exactly one 16-lane env group, so these are single full-rate VALU modifiers instead of ds_bpermute round trips
+template <int CTRL, bool ZERO_OOB> __device__ __forceinline__ float dpp_f(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, ZERO_OOB));
+}
+template <int CTRL, bool ZERO_OOB> __device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, ZERO_OOB); }
+// value of lane LANE of the group, in every lane of the group
+template <int G, int LANE> __device__ __forceinline__ float gbcast(float v) {
+    if constexpr (G == 16) return dpp_f<0x150 + LANE, false>(v); else return __shfl(v, LANE, G);
+}
 template <int G> __device__ __forceinline__ float gsum(float v) {
+    if constexpr (G == 16) {
+        v += dpp_f<0x128, false>(v); v += dpp_f<0x124, false>(v); v += dpp_f<0x122, false>(v); v += dpp_f<0x121, false>(v);
+        return v;
+    } else {
 #pragma unroll
-    for (int off = G / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, G);
-    return v;
+        for (int off = G / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, G);
+        return v;
+    }
 }
 template <int G> __device__ __forceinline__ int gscan_incl(int v, int c) {
+    if constexpr (G == 16) {
+        v += dpp_i<0x111, true>(v); v += dpp_i<0x112, true>(v); v += dpp_i<0x114, true>(v); v += dpp_i<0x118, true>(v);
+        return v;
+    } else {
 #pragma unroll
-    for (int off = 1; off < G; off <<= 1) { const int t = __shfl_up(v, off, G); if (c >= off) v += t; }
-    return v;
+        for (int off = 1; off < G; off <<= 1) { const int t = __shfl_up(v, off, G); if (c >= off) v += t; }
+        return v;
+    }
+}
+template <int G> __device__ __forceinline__ int glast(int v) {   // value of the last lane of the group
+    if constexpr (G == 16) return dpp_i<0x15F, false>(v); else return __shfl(v, G - 1, G);
 }
 
 // in-register cooperative Cholesky: lane c holds row c (entries k <= c) of an SPD matrix; on return row c of L
-template <int G> __device__ __forceinline__ bool chol_g(float (&row)[G], int nv, int c) {
+// and invd = 1 / L[c][c]
+template <int G> __device__ __forceinline__ bool chol_g(float (&row)[G], float &invd, int nv, int c) {
     bool ok = true;
-#pragma unroll
-    for (int j = 0; j < G; j++) {
+    invd = 1.f;
+    static_for<0, G>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
         if (j < nv) {
-            float ajj = __shfl(row[j], j, G);
+            float ajj = gbcast<G, j>(row[j]);
             if (!(ajj >= HSR_MINVAL)) { ok = false; ajj = 1.f; }
-            const float d = sqrtf(ajj), inv = 1.0f / d;
+            const float d = sqrtf(ajj), inv = __builtin_amdgcn_rcpf(d);
             const float lcj = (c == j) ? d : row[j] * inv;
+            if (c == j) invd = inv;
             row[j] = lcj;
-#pragma unroll
-            for (int i = j + 1; i < G; i++) {
-                const float li = __shfl(lcj, i, G);
+            static_for<j + 1, G>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                const float li = gbcast<G, i>(lcj);
                 if (i <= c) row[i] -= lcj * li;
-            }
+            });
         }
-    }
+    });
     return ok;
 }
-// solve L L^T x = b with lane c holding row c of L and b_c; tile = G*(G+1) floats of LDS scratch.
+// solve L L^T x = b with lane c holding row c of L, invd and b_c; tile = G*(G+1) floats of LDS scratch.
 // Contains two workgroup barriers: must be called by every thread of the block.
-template <int G> __device__ __forceinline__ float chol_solve_g(const float (&row)[G], float b, int nv, int c, float *tile) {
+template <int G> __device__ __forceinline__ float chol_solve_g(const float (&row)[G], float invd, float b, int nv, int c, float *tile) {
     float sacc = b, y = 0.f;
-#pragma unroll
-    for (int j = 0; j < G; j++) {
+    static_for<0, G>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
         if (j < nv) {
-            const float yj = __shfl(sacc / row[j], j, G);
+            const float yj = gbcast<G, j>(sacc * invd);
             if (c == j) y = yj;
             if (c > j) sacc -= row[j] * yj;
         }
-    }
+    });
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < G; k++) tile[c * (G + 1) + k] = (k <= c) ? row[k] : 0.f;
@@ -65,14 +102,14 @@ template <int G> __device__ __forceinline__ float chol_solve_g(const float (&row
 #pragma unroll
     for (int k = 0; k < G; k++) lt[k] = tile[k * (G + 1) + c];      // L[k][c]
     float s2 = y, x = 0.f;
-#pragma unroll
-    for (int j = G - 1; j >= 0; j--) {
+    static_for<0, G>([&](auto jc) {
+        constexpr int j = G - 1 - decltype(jc)::value;
         if (j < nv) {
-            const float xj = __shfl(s2 / lt[j], j, G);
+            const float xj = gbcast<G, j>(s2 * invd);
             if (c == j) x = xj;
             if (c < j) s2 -= lt[j] * xj;
         }
-    }
+    });
     return x;
 }
 
@@ -114,24 +151,27 @@ __device__ __forceinline__ void cone_eval2(int dim, float mu, const float *fri, 
 
 // per-contact record in LDS (floats)
 enum { CR_POS = 0, CR_N = 3, CR_T1 = 6, CR_T2 = 9, CR_DIST = 12, CR_MU = 13, CR_PAIR = 14, CR_ADR = 15, CR_DIM = 16,
-       CR_ZONE = 17, CR_DM = 18, CR_K3 = 19, CR_GN = 20, CR_U = 26, CR_L1 = 32, CR_L2 = 33, CR_B = 34, CR_KD = 35, CR_SIZE = 36 };
-enum { NLMAX = 16, NVEC = 12 };
+       CR_ZONE = 17, CR_DM = 18, CR_K3 = 19, CR_GN = 20, CR_U = 26, CR_L1 = 32, CR_L2 = 33, CR_B = 34, CR_KD = 35, CR_FRI = 36, CR_SIZE = 41 };
+enum { NLMAX = 16, NVEC = 8 };
 
+// LDS floats of one env.  Transient tables alias longer-lived regions:
+//   kin axes + link table live inside the (not yet written) Jacobian region during phases A-C,
+//   the inertia matrix M shares the Cholesky-solve tile (M is copied to registers before the first solve).
 template <int G> struct SolveLayout {
     int R, RS, MS, oJ, oD, oAref, oJar, oJv, oGr, oDw, oVec, oM, oTile, oAng, oLin, oAnc, oLk, oCon, total;
     __host__ __device__ SolveLayout(int rows) {
         R = rows; RS = G + 4; MS = G + 1;
         int o = 0;
-        oJ = o; o += R * RS;
+        oJ = o;
+        oAng = o; oLin = oAng + 3 * G; oAnc = oLin + 3 * G; oLk = oAnc + 3 * G;       // 9G + 15*NLMAX <= R*RS (checked on host)
+        o += R * RS;
         oD = o; o += R; oAref = o; o += R; oJar = o; o += R; oJv = o; o += R; oGr = o; o += R; oDw = o; o += R;
         oVec = o; o += NVEC * G;
-        oM = o; o += G * MS;
-        oTile = o; o += G * MS;
-        oAng = o; o += 3 * G; oLin = o; o += 3 * G; oAnc = o; o += 3 * G;
-        oLk = o; o += 15 * NLMAX;
+        oM = o; oTile = o; o += G * MS;
         oCon = o; o += CR_SIZE * G;
         total = (o + 3) & ~3;
     }
+    __host__ __device__ bool fits() const { return 9 * G + 15 * NLMAX <= R * RS; }
 };
 
 template <int G>
@@ -152,40 +192,75 @@ __global__ void __launch_bounds__(64) k_solve_g(DevModel m, DevState s, int mode
     float *M = E + L.oM, *tile = E + L.oTile, *kAng = E + L.oAng, *kLin = E + L.oLin, *kAnc = E + L.oAnc, *lk = E + L.oLk, *con = E + L.oCon;
     const bool isdof = c < nv;
     int bad = 0;
+    // model constants used inside loops: one copy per workgroup in LDS (no dependent global loads later)
+    __shared__ int sParent[32], sMask[NLMAX];
+    __shared__ float sMass[NLMAX];
+    if (tid < nv) sParent[tid] = m.dof_parent[tid];
+    if (tid < m.nlink && tid < NLMAX) { sMask[tid] = m.link_dofmask[tid]; sMass[tid] = m.link_mass[tid]; }
 
-    // ---------------- phase A: stage per-env inputs into LDS
+    PHASE_T0();
+    // ---------------- phase A: every first-level global load of the kernel is issued here, back to back, so that
+    // their (fabric / Infinity-Cache) latencies overlap; the data was written by the previous kernels.
+    constexpr int MAXCH = 256 / G;                         // pair-count chunks of G pairs (npair <= 256)
+    int cnt_ch[MAXCH];
+    {
+        const int *cp = s.ncon_pair + (size_t)e * m.npair_pad;
+#pragma unroll
+        for (int ch = 0; ch < MAXCH; ch++) { const int p = ch * G + c; cnt_ch[ch] = (valid && p < m.npair) ? cp[p] : 0; }
+    }
     v3 a_c = mk3(0, 0, 0), l_c = mk3(0, 0, 0), n_c = mk3(0, 0, 0);
-    float qvel_c = 0, warm_c = 0;
+    float qvel_c = 0, warm_c = 0, my_q = 0, my_ctrl = 0, damp_c = 0;
+    int my_type = -1, my_qadr = 0, my_quat_lane = -1, my_limited = 0, my_act = -1;
+    float lim_lo = 0, lim_hi = 0, lim_sr0 = 1, lim_sr1 = 1, lim_iw = 0, lim_si[5] = {0, 0, 0, 0, 0};
+    float act_p[7] = {0, 0, 0, 0, 0, 0, 0};
     if (isdof) {
+        my_type = m.dof_type[c]; my_qadr = m.dof_qposadr[c]; my_limited = m.dof_limited[c]; my_act = m.dof_act[c];
+        my_quat_lane = m.link_dofadr[m.dof_link[c]] + 3;
+        damp_c = m.dof_damping[c];
         qvel_c = s.qvel[(size_t)c * N + e]; warm_c = s.warm[(size_t)c * N + e];
         View ang{s.dof_ang + e, N}, lin{s.dof_lin + e, N}, anc{s.dof_anchor + e, N};
         a_c = ang.get3(c); l_c = lin.get3(c); n_c = anc.get3(c);
-        if (!(fabsf(qvel_c) <= 1e10f)) bad = 1;
+        lim_lo = m.dof_range[2 * c]; lim_hi = m.dof_range[2 * c + 1]; lim_sr0 = m.dof_solref[2 * c]; lim_sr1 = m.dof_solref[2 * c + 1];
+        lim_iw = m.dof_invweight0[c];
+#pragma unroll
+        for (int j = 0; j < 5; j++) lim_si[j] = m.dof_solimp[5 * c + j];
+        my_q = s.qpos[(size_t)my_qadr * N + e];
+        if (my_act >= 0) {
+            my_ctrl = s.ctrl[(size_t)my_act * N + e];
+            act_p[0] = m.act_kp[my_act]; act_p[1] = m.act_gear[my_act];
+            act_p[2] = m.act_ctrlrange[2 * my_act]; act_p[3] = m.act_ctrlrange[2 * my_act + 1];
+            act_p[4] = m.act_forcerange[2 * my_act]; act_p[5] = m.act_forcerange[2 * my_act + 1];
+        }
+        if (!(fabsf(qvel_c) <= 1e10f) || !(fabsf(my_q) <= 1e10f)) bad = 1;
     }
+    float lkreg[15];
+#pragma unroll
+    for (int k = 0; k < 15; k++) lkreg[k] = (c < m.nlink && c < NLMAX) ? s.link_dyn[(size_t)(15 * c + k) * N + e] : 0.f;
     vQvel[c] = qvel_c; vWarm[c] = warm_c;
     kAng[3 * c] = a_c.x; kAng[3 * c + 1] = a_c.y; kAng[3 * c + 2] = a_c.z;
     kLin[3 * c] = l_c.x; kLin[3 * c + 1] = l_c.y; kLin[3 * c + 2] = l_c.z;
     kAnc[3 * c] = n_c.x; kAnc[3 * c + 1] = n_c.y; kAnc[3 * c + 2] = n_c.z;
-    if (c < m.nlink && c < NLMAX) {
+    if (c < NLMAX) {
 #pragma unroll
-        for (int k = 0; k < 15; k++) lk[15 * c + k] = s.link_dyn[(size_t)(15 * c + k) * N + e];
+        for (int k = 0; k < 15; k++) lk[15 * c + k] = lkreg[k];
     }
 #pragma unroll
     for (int k = 0; k < G + 1; k++) M[c * MS + k] = 0.f;
     __syncthreads();
 
+    PHASE(0);
     // ---------------- phase B/C: inertia rows (a-2.2) and bias force (a-2.5), lane = dof
     float bias_c = 0;
     if (isdof) {
         for (int l = 1; l < m.nlink; l++) {
-            if (!((m.link_dofmask[l] >> c) & 1)) continue;
+            if (!((sMask[l] >> c) & 1)) continue;
             const float *q = lk + 15 * l;
             const v3 com = mk3(q[0], q[1], q[2]), F = mk3(q[9], q[10], q[11]), Nt = mk3(q[12], q[13], q[14]);
             const v3 jpc = l_c + cross(a_c, com - n_c);
-            const v3 v = jpc * m.link_mass[l];
+            const v3 v = jpc * sMass[l];
             const v3 u = mk3(q[3] * a_c.x + q[6] * a_c.y + q[7] * a_c.z, q[6] * a_c.x + q[4] * a_c.y + q[8] * a_c.z, q[7] * a_c.x + q[8] * a_c.y + q[5] * a_c.z);
             bias_c += dot(jpc, F) + dot(a_c, Nt);
-            for (int k = c; k >= 0; k = m.dof_parent[k]) {
+            for (int k = c; k >= 0; k = sParent[k]) {
                 const v3 ak = mk3(kAng[3 * k], kAng[3 * k + 1], kAng[3 * k + 2]);
                 const v3 jpk = mk3(kLin[3 * k], kLin[3 * k + 1], kLin[3 * k + 2]) + cross(ak, com - mk3(kAnc[3 * k], kAnc[3 * k + 1], kAnc[3 * k + 2]));
                 M[c * MS + k] += dot(jpk, v) + dot(ak, u);
@@ -193,24 +268,24 @@ __global__ void __launch_bounds__(64) k_solve_g(DevModel m, DevState s, int mode
         }
     }
     float qfs_c = 0;
-    const float damp_c = isdof ? m.dof_damping[c] : 0.f;
     if (isdof) {
         qfs_c = -damp_c * qvel_c - bias_c;
-        for (int a = 0; a < m.nu; a++) if (m.act_dof[a] == c) {
-            const float q = s.qpos[(size_t)m.dof_qposadr[c] * N + e];
-            const float ct = fminf(fmaxf(s.ctrl[(size_t)a * N + e], m.act_ctrlrange[2 * a]), m.act_ctrlrange[2 * a + 1]);
-            float f = m.act_kp[a] * ct - m.act_kp[a] * m.act_gear[a] * q;
-            f = fminf(fmaxf(f, m.act_forcerange[2 * a]), m.act_forcerange[2 * a + 1]);
-            qfs_c += m.act_gear[a] * f;
+        if (my_act >= 0) {
+            // position actuator: force = kp*clamp(ctrl) - kp*gear*q, clamped to forcerange; qfrc = gear*force
+            const float ct = fminf(fmaxf(my_ctrl, act_p[2]), act_p[3]);
+            float f = act_p[0] * ct - act_p[0] * act_p[1] * my_q;
+            f = fminf(fmaxf(f, act_p[4]), act_p[5]);
+            qfs_c += act_p[1] * f;
         }
     }
     vQfs[c] = qfs_c;
     __syncthreads();
-    if (isdof) for (int k = m.dof_parent[c]; k >= 0; k = m.dof_parent[k]) M[k * MS + c] = M[c * MS + k];   // mirror
+    if (isdof) for (int k = sParent[c]; k >= 0; k = sParent[k]) M[k * MS + c] = M[c * MS + k];   // mirror
     if (!isdof) M[c * MS + c] = 1.f;
     __syncthreads();
     if (debug && valid && isdof) for (int k = 0; k <= c; k++) s.M[(size_t)(c * (c + 1) / 2 + k) * N + e] = M[c * MS + k];
 
+    PHASE(1);
     // ---------------- qacc_smooth = M^-1 qfrc_smooth
     float Mrow[G];
 #pragma unroll
@@ -220,36 +295,35 @@ __global__ void __launch_bounds__(64) k_solve_g(DevModel m, DevState s, int mode
         float Lr[G];
 #pragma unroll
         for (int k = 0; k < G; k++) Lr[k] = Mrow[k];
-        if (!chol_g<G>(Lr, nv, c)) bad = 1;
-        qas_c = chol_solve_g<G>(Lr, qfs_c, nv, c, tile);
+        float invd;
+        if (!chol_g<G>(Lr, invd, nv, c)) bad = 1;
+        qas_c = chol_solve_g<G>(Lr, invd, qfs_c, nv, c, tile);
         if (!isdof) qas_c = 0;
     }
     vQas[c] = qas_c;
 
+    PHASE(2);
     // ---------------- phase E: constraint assembly (a-2.4)
     // E1 joint limits, lane = dof, rows in dof order (lower side then upper side)
     int nlim;
     {
         int a0 = 0, a1 = 0;
         float dlo = 0, dhi = 0;
-        if (valid && isdof && m.dof_limited[c]) {
-            const float q = s.qpos[(size_t)m.dof_qposadr[c] * N + e];
-            if (!(fabsf(q) <= 1e10f)) bad = 1;
-            dlo = q - m.dof_range[2 * c]; dhi = m.dof_range[2 * c + 1] - q;
+        if (valid && my_limited) {
+            dlo = my_q - lim_lo; dhi = lim_hi - my_q;
             a0 = dlo < 0; a1 = dhi < 0;
         }
         const int incl = gscan_incl<G>(a0 + a1, c);
-        nlim = __shfl(incl, G - 1, G);
+        nlim = glast<G>(incl);
         int r = incl - (a0 + a1);
 #pragma unroll
         for (int side = 0; side < 2; side++) {
             if ((side == 0 ? a0 : a1) && r < R) {
                 const float dist = side == 0 ? dlo : dhi, sg = side == 0 ? 1.f : -1.f;
-                const float imp = impedance(m.dof_solimp + 5 * c, dist);
-                const float dmax = fminf(fmaxf(m.dof_solimp[5 * c + 1], HSR_MINIMP), HSR_MAXIMP);
-                const float tc = m.dof_solref[2 * c], dr = m.dof_solref[2 * c + 1];
-                const float Kimp = imp / (dmax * dmax * tc * tc * dr * dr), B = 2.0f / (dmax * tc);
-                const float Rr = fmaxf((1 - imp) / imp * m.dof_invweight0[c], HSR_MINVAL);
+                const float imp = impedance(lim_si, dist);
+                const float dmax = fminf(fmaxf(lim_si[1], HSR_MINIMP), HSR_MAXIMP);
+                const float Kimp = imp / (dmax * dmax * lim_sr0 * lim_sr0 * lim_sr1 * lim_sr1), B = 2.0f / (dmax * lim_sr0);
+                const float Rr = fmaxf((1 - imp) / imp * lim_iw, HSR_MINVAL);
                 for (int k = 0; k < G; k++) J[r * RS + k] = (k == c) ? sg : 0.f;
                 rAref[r] = -B * sg * qvel_c - Kimp * dist;
                 rD[r] = 1.0f / Rr;
@@ -262,27 +336,39 @@ __global__ void __launch_bounds__(64) k_solve_g(DevModel m, DevState s, int mode
     int ncon = 0;
     {
         int base = 0;
-        for (int p0 = 0; p0 < m.npair; p0 += G) {
-            const int p = p0 + c;
-            const int cnt = (valid && p < m.npair) ? s.ncon_pair[(size_t)p * N + e] : 0;
-            const int incl = gscan_incl<G>(cnt, c);
-            const int tot = __shfl(incl, G - 1, G);
-            for (int i = 0; i < cnt; i++) {
-                const int ci = base + incl - cnt + i;
-                if (ci < G) { float *cr = con + CR_SIZE * ci; cr[CR_PAIR] = (float)p; cr[CR_ZONE] = (float)(m.pair_slot[p] + i); }   // ZONE slot reused for the source slot
+#pragma unroll
+        for (int ch = 0; ch < MAXCH; ch++) {
+            if (ch * G < m.npair) {
+                const int p = ch * G + c, cnt = cnt_ch[ch];
+                const int incl = gscan_incl<G>(cnt, c);
+                const int tot = glast<G>(incl);
+                if (cnt > 0) {
+                    const int slot0 = m.pair_slot[p];
+                    for (int i = 0; i < cnt; i++) {
+                        const int ci = base + incl - cnt + i;
+                        if (ci < G) { float *cr = con + CR_SIZE * ci; cr[CR_PAIR] = (float)p; cr[CR_ZONE] = (float)(slot0 + i); }   // ZONE reused for the source slot
+                    }
+                }
+                base += tot;
             }
-            base += tot;
         }
         ncon = base < G ? base : G;
         if (ncon > m.nconmax) ncon = m.nconmax;
     }
     __syncthreads();
+    PHASE(3);
     // E3 lane = contact: frame, impedance, regulariser, row addresses
     {
         int dim = 0;
         float *cr = con + CR_SIZE * c;
-        int p = 0;
-        if (c < ncon) { p = (int)cr[CR_PAIR]; dim = m.pair_condim[p]; }
+        float4 pr[4] = {make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0)}, cd0 = make_float4(0, 0, 0, 0), cd1 = cd0;
+        if (c < ncon) {
+            const int p = (int)cr[CR_PAIR], slot = (int)cr[CR_ZONE];
+            const float4 *prp = reinterpret_cast<const float4 *>(m.pair_rec + 16 * p);
+            const float4 *cdp = reinterpret_cast<const float4 *>(s.con + ((size_t)e * m.nslot + slot) * 8);
+            pr[0] = prp[0]; pr[1] = prp[1]; pr[2] = prp[2]; pr[3] = prp[3]; cd0 = cdp[0]; cd1 = cdp[1];
+            dim = (int)pr[0].x;
+        }
         const int incl = gscan_incl<G>(dim, c);
         const int adr = nlim + incl - dim;
         const bool ovf = c < ncon && adr + dim > R;
@@ -291,19 +377,15 @@ __global__ void __launch_bounds__(64) k_solve_g(DevModel m, DevState s, int mode
         const unsigned int gm = (unsigned int)((bal >> (g * G)) & ((G == 32) ? 0xffffffffull : 0xffffull));
         if (gm) ncon = __ffs(gm) - 1;
         if (c < ncon) {
-            const int slot = (int)cr[CR_ZONE];
-            View cs{s.con + e, N};
-            const int b = slot * 7;
-            const v3 pos = mk3(cs[b], cs[b + 1], cs[b + 2]), nrm = mk3(cs[b + 3], cs[b + 4], cs[b + 5]);
-            const float dist = cs[b + 6];
+            const v3 pos = mk3(cd0.x, cd0.y, cd0.z), nrm = mk3(cd0.w, cd1.x, cd1.y);
+            const float dist = cd1.z;
             v3 t1 = (nrm.y > -0.5f && nrm.y < 0.5f) ? mk3(0, 1, 0) : mk3(0, 0, 1);
             t1 = normalized(t1 - nrm * dot(nrm, t1));
             const v3 t2 = cross(nrm, t1);
-            const int g1 = m.pair_geom1[p], g2 = m.pair_geom2[p];
-            const float *solref = m.pair_solref + 2 * p, *solimp = m.pair_solimp + 5 * p, *fri = m.pair_friction + 5 * p;
+            const float fri[5] = {pr[1].x, pr[1].y, pr[1].z, pr[1].w, pr[2].x};
+            const float solimp[5] = {pr[2].w, pr[3].x, pr[3].y, pr[3].z, pr[3].w};
+            const float tc = pr[2].y, dr = pr[2].z, tran = pr[0].w;
             const float imp = impedance(solimp, dist), dmax = fminf(fmaxf(solimp[1], HSR_MINIMP), HSR_MAXIMP);
-            const float tc = solref[0], dr = solref[1];
-            const float tran = m.geom_invweight[2 * g1] + m.geom_invweight[2 * g2];
             const float B = 2.0f / (dmax * tc), Kimp = imp / (dmax * dmax * tc * tc * dr * dr);
             const float R0 = fmaxf((1 - imp) / imp * tran, HSR_MINVAL), R1 = R0 / fmaxf(m.impratio, HSR_MINVAL);
             cr[CR_POS] = pos.x; cr[CR_POS + 1] = pos.y; cr[CR_POS + 2] = pos.z;
@@ -312,8 +394,10 @@ __global__ void __launch_bounds__(64) k_solve_g(DevModel m, DevState s, int mode
             cr[CR_T2] = t2.x; cr[CR_T2 + 1] = t2.y; cr[CR_T2 + 2] = t2.z;
             cr[CR_DIST] = dist; cr[CR_MU] = dim > 1 ? fri[0] * sqrtf(R1 / R0) : fri[0];
             cr[CR_ADR] = (float)adr; cr[CR_DIM] = (float)dim;
-            cr[CR_L1] = (float)m.geom_link[g1]; cr[CR_L2] = (float)m.geom_link[g2];
+            cr[CR_L1] = pr[0].y; cr[CR_L2] = pr[0].z;
             cr[CR_B] = B; cr[CR_KD] = Kimp * dist;
+#pragma unroll
+            for (int j = 0; j < 5; j++) cr[CR_FRI + j] = fri[j];
             for (int j = 0; j < dim; j++) {
                 const float Rj = j == 0 ? R0 : (j == 1 ? R1 : R1 * fri[0] * fri[0] / (fri[j - 1] * fri[j - 1]));
                 rD[adr + j] = 1.0f / Rj;
@@ -321,12 +405,13 @@ __global__ void __launch_bounds__(64) k_solve_g(DevModel m, DevState s, int mode
         }
     }
     __syncthreads();
+    PHASE(4);
     // E4 lane = dof column: Jacobian entries of every contact row
     int nefc = nlim;
     for (int ci = 0; ci < ncon; ci++) {
         const float *cr = con + CR_SIZE * ci;
         const int adr = (int)cr[CR_ADR], dim = (int)cr[CR_DIM], l1 = (int)cr[CR_L1], l2 = (int)cr[CR_L2];
-        const int in1 = (m.link_dofmask[l1] >> c) & 1, in2 = (m.link_dofmask[l2] >> c) & 1;
+        const int in1 = (sMask[l1] >> c) & 1, in2 = (sMask[l2] >> c) & 1;
         const float sg = (float)(in2 - in1);
         const v3 pos = mk3(cr[CR_POS], cr[CR_POS + 1], cr[CR_POS + 2]);
         const v3 vp = (l_c + cross(a_c, pos - n_c)) * sg, wr = a_c * sg;
@@ -350,6 +435,7 @@ __global__ void __launch_bounds__(64) k_solve_g(DevModel m, DevState s, int mode
     }
     __syncthreads();
 
+    PHASE(5);
     // ---------------- phase F: Newton solver (a-2.6)
     const float tol = m.tolerance, scale = 1.0f / (m.meaninertia * (nv > 1 ? nv : 1));
     float cost = 0, Ma_c = 0;
@@ -372,10 +458,10 @@ __global__ void __launch_bounds__(64) k_solve_g(DevModel m, DevState s, int mode
         __syncthreads();
         if (c < ncon) {
             float *cr = con + CR_SIZE * c;
-            const int adr = (int)cr[CR_ADR], dim = (int)cr[CR_DIM], p = (int)cr[CR_PAIR];
+            const int adr = (int)cr[CR_ADR], dim = (int)cr[CR_DIM];
             float D[6], x[6], fri[5];
 #pragma unroll
-            for (int j = 0; j < 5; j++) fri[j] = m.pair_friction[5 * p + j];
+            for (int j = 0; j < 5; j++) fri[j] = cr[CR_FRI + j];
 #pragma unroll
             for (int j = 0; j < 6; j++) if (j < dim) { D[j] = rD[adr + j]; x[j] = rJar[adr + j]; } else { D[j] = 0; x[j] = 0; }
             ConeOut o;
@@ -402,6 +488,7 @@ __global__ void __launch_bounds__(64) k_solve_g(DevModel m, DevState s, int mode
         if (__syncthreads_or(!use_warm)) cost = eval_at(vQacc);
         __syncthreads();
     }
+    PHASE(6);
     for (int it = 0; it < m.iterations; it++) {
         if (!__syncthreads_or(active)) break;
         // gradient, lane = dof
@@ -412,6 +499,7 @@ __global__ void __launch_bounds__(64) k_solve_g(DevModel m, DevState s, int mode
         }
         const float gnorm = sqrtf(gsum<G>(grad_c * grad_c));
         if (scale * gnorm < tol) active = false;
+        PHASE(7);
         // Hessian rows H = M + J^T (d2s) J, lane = row c of H
         float Hrow[G];
 #pragma unroll
@@ -436,23 +524,26 @@ __global__ void __launch_bounds__(64) k_solve_g(DevModel m, DevState s, int mode
                 float pc = 0, wc = 0;
                 for (int j = 0; j < dim; j++) { const float jc = J[(adr + j) * RS + c]; pc += jc * cr[CR_GN + j]; wc += jc * cr[CR_U + j]; }
                 const float Dm = cr[CR_DM], k3 = cr[CR_K3];
-#pragma unroll
-                for (int k = 0; k < G; k++) {
-                    const float pk = __shfl(pc, k, G), wk = __shfl(wc, k, G);
+                static_for<0, G>([&](auto kc) {
+                    constexpr int k = decltype(kc)::value;
+                    const float pk = gbcast<G, k>(pc), wk = gbcast<G, k>(wc);
                     Hrow[k] += Dm * pc * pk - k3 * wc * wk;
-                }
+                });
             }
         }
         if (!isdof) {
 #pragma unroll
             for (int k = 0; k < G; k++) Hrow[k] = (k == c) ? 1.f : 0.f;
         }
-        if (!chol_g<G>(Hrow, nv, c) && active) { bad = 1; active = false; }
-        float search_c = chol_solve_g<G>(Hrow, -grad_c, nv, c, tile);
+        PHASE(8);
+        float hinvd;
+        if (!chol_g<G>(Hrow, hinvd, nv, c) && active) { bad = 1; active = false; }
+        float search_c = chol_solve_g<G>(Hrow, hinvd, -grad_c, nv, c, tile);
         if (!isdof) search_c = 0;
         __syncthreads();
         vSearch[c] = search_c;
         __syncthreads();
+        PHASE(9);
         // exact line search (safeguarded 1-D Newton on phi'), all reductions by shuffles
         float mv = 0;
 #pragma unroll
@@ -471,10 +562,10 @@ __global__ void __launch_bounds__(64) k_solve_g(DevModel m, DevState s, int mode
             int cdim = 0;
             if (c < ncon) {
                 const float *cr = con + CR_SIZE * c;
-                const int adr = (int)cr[CR_ADR], p = (int)cr[CR_PAIR];
+                const int adr = (int)cr[CR_ADR];
                 cdim = (int)cr[CR_DIM]; cmu = cr[CR_MU];
 #pragma unroll
-                for (int j = 0; j < 5; j++) cfri[j] = m.pair_friction[5 * p + j];
+                for (int j = 0; j < 5; j++) cfri[j] = cr[CR_FRI + j];
 #pragma unroll
                 for (int j = 0; j < 6; j++) if (j < cdim) { cD[j] = rD[adr + j]; cx[j] = rJar[adr + j]; cv[j] = rJv[adr + j]; } else { cD[j] = 0; cx[j] = 0; cv[j] = 0; }
             }
@@ -518,10 +609,12 @@ __global__ void __launch_bounds__(64) k_solve_g(DevModel m, DevState s, int mode
                 if (!(alpha > 0)) { active = false; alpha = 0; }
             }
         }
+        PHASE(10);
         if (active) vQacc[c] += alpha * search_c;
         __syncthreads();
         const float newcost = eval_at(vQacc);
         if (active) { iter++; cost = newcost; }
+        PHASE(11);
     }
     float qacc_c = vQacc[c], qfc_c = 0;
     if (nefc == 0) qacc_c = qas_c;
@@ -537,6 +630,7 @@ __global__ void __launch_bounds__(64) k_solve_g(DevModel m, DevState s, int mode
         return;
     }
 
+    PHASE(12);
     // ---------------- phase G: mj_Euler (a-2.7): implicit joint damping, semi-implicit update
     const float h = m.timestep;
     float acc_c = qacc_c;
@@ -544,8 +638,9 @@ __global__ void __launch_bounds__(64) k_solve_g(DevModel m, DevState s, int mode
         float Ar[G];
 #pragma unroll
         for (int k = 0; k < G; k++) Ar[k] = Mrow[k] + ((k == c) ? h * damp_c : 0.f);
-        if (!chol_g<G>(Ar, nv, c)) bad = 1;
-        acc_c = chol_solve_g<G>(Ar, qfs_c + qfc_c, nv, c, tile);
+        float ainvd;
+        if (!chol_g<G>(Ar, ainvd, nv, c)) bad = 1;
+        acc_c = chol_solve_g<G>(Ar, ainvd, qfs_c + qfc_c, nv, c, tile);
     }
     const float vnew = qvel_c + h * acc_c;
     if (!(fabsf(vnew) <= 1e10f) && isdof) bad = 1;
@@ -555,10 +650,10 @@ __global__ void __launch_bounds__(64) k_solve_g(DevModel m, DevState s, int mode
     if (valid && isdof) {
         s.qvel[(size_t)c * N + e] = vnew;
         s.warm[(size_t)c * N + e] = qacc_c;
-        const int t = m.dof_type[c];
-        const int adr = m.dof_qposadr[c];
-        if (t == DOF_SLIDE || t == DOF_HINGE || t == DOF_FREE_LIN) s.qpos[(size_t)adr * N + e] += h * vnew;
-        else if (c == m.link_dofadr[m.dof_link[c]] + 3) {
+        const int t = my_type;
+        const int adr = my_qadr;
+        if (t == DOF_SLIDE || t == DOF_HINGE || t == DOF_FREE_LIN) s.qpos[(size_t)adr * N + e] = my_q + h * vnew;
+        else if (c == my_quat_lane) {
             // first rotational dof of a free joint integrates the quaternion (mju_quatIntegrate)
             const v3 w = mk3(vSearch[c], vSearch[c + 1], vSearch[c + 2]);
             const float wn = norm(w), angle = wn * h;
@@ -574,6 +669,7 @@ __global__ void __launch_bounds__(64) k_solve_g(DevModel m, DevState s, int mode
             }
         }
     }
+    PHASE(13);
     const float bsum = gsum<G>((float)bad);
     if (valid && c == 0) {
         s.time[e] += h;

@@ -15,7 +15,8 @@ import numpy as np
 from .compiler import Model
 
 _HERE = Path(__file__).parent
-LIB_PATH = _HERE / "libhsrsim.so"
+import os
+LIB_PATH = Path(os.environ.get("HSR_LIB", _HERE / "libhsrsim.so"))
 
 
 class DependencyNotInstalled(ImportError):
