@@ -500,44 +500,56 @@ __global__ void __launch_bounds__(64) k_solve_g(DevModel m, DevState s, int mode
         const float gnorm = sqrtf(gsum<G>(grad_c * grad_c));
         if (scale * gnorm < tol) active = false;
         PHASE(7);
-        // Hessian rows H = M + J^T (d2s) J, lane = row c of H
+        // Hessian rows H = M + J^T (d2s) J, lane = row c of H.  with_neg = false drops the negative rank-1 part
+        // of the middle-zone cone Hessians (a PSD majorant), used only if the fp32 factorisation fails.
         float Hrow[G];
+        auto build_H = [&](bool with_neg) {
 #pragma unroll
-        for (int k = 0; k < G; k++) Hrow[k] = Mrow[k];
-        if (active) {
-            for (int r = 0; r < nefc; r++) {
-                const float w = rDw[r];
-                if (w != 0.f) {
-                    const float t = w * J[r * RS + c];
-                    const float4 *jr = reinterpret_cast<const float4 *>(J + r * RS);
+            for (int k = 0; k < G; k++) Hrow[k] = Mrow[k];
+            if (active) {
+                for (int r = 0; r < nefc; r++) {
+                    const float w = rDw[r];
+                    if (w != 0.f) {
+                        const float t = w * J[r * RS + c];
+                        const float4 *jr = reinterpret_cast<const float4 *>(J + r * RS);
 #pragma unroll
-                    for (int k4 = 0; k4 < G / 4; k4++) {
-                        const float4 q = jr[k4];
-                        Hrow[4 * k4] += t * q.x; Hrow[4 * k4 + 1] += t * q.y; Hrow[4 * k4 + 2] += t * q.z; Hrow[4 * k4 + 3] += t * q.w;
+                        for (int k4 = 0; k4 < G / 4; k4++) {
+                            const float4 q = jr[k4];
+                            Hrow[4 * k4] += t * q.x; Hrow[4 * k4 + 1] += t * q.y; Hrow[4 * k4 + 2] += t * q.z; Hrow[4 * k4 + 3] += t * q.w;
+                        }
                     }
                 }
+                for (int ci = 0; ci < ncon; ci++) {
+                    const float *cr = con + CR_SIZE * ci;
+                    if ((int)cr[CR_ZONE] != 2) continue;
+                    const int adr = (int)cr[CR_ADR], dim = (int)cr[CR_DIM];
+                    float pc = 0, wc = 0;
+                    for (int j = 0; j < dim; j++) { const float jc = J[(adr + j) * RS + c]; pc += jc * cr[CR_GN + j]; wc += jc * cr[CR_U + j]; }
+                    const float Dm = cr[CR_DM], k3 = with_neg ? cr[CR_K3] : 0.f;
+                    static_for<0, G>([&](auto kc) {
+                        constexpr int k = decltype(kc)::value;
+                        const float pk = gbcast<G, k>(pc), wk = gbcast<G, k>(wc);
+                        Hrow[k] += Dm * pc * pk - k3 * wc * wk;
+                    });
+                }
             }
-            for (int ci = 0; ci < ncon; ci++) {
-                const float *cr = con + CR_SIZE * ci;
-                if ((int)cr[CR_ZONE] != 2) continue;
-                const int adr = (int)cr[CR_ADR], dim = (int)cr[CR_DIM];
-                float pc = 0, wc = 0;
-                for (int j = 0; j < dim; j++) { const float jc = J[(adr + j) * RS + c]; pc += jc * cr[CR_GN + j]; wc += jc * cr[CR_U + j]; }
-                const float Dm = cr[CR_DM], k3 = cr[CR_K3];
-                static_for<0, G>([&](auto kc) {
-                    constexpr int k = decltype(kc)::value;
-                    const float pk = gbcast<G, k>(pc), wk = gbcast<G, k>(wc);
-                    Hrow[k] += Dm * pc * pk - k3 * wc * wk;
-                });
-            }
-        }
-        if (!isdof) {
+            if (!isdof) {
 #pragma unroll
-            for (int k = 0; k < G; k++) Hrow[k] = (k == c) ? 1.f : 0.f;
-        }
+                for (int k = 0; k < G; k++) Hrow[k] = (k == c) ? 1.f : 0.f;
+            }
+        };
+        PHASE(7);
+        build_H(true);
         PHASE(8);
         float hinvd;
-        if (!chol_g<G>(Hrow, hinvd, nv, c) && active) { bad = 1; active = false; }
+        bool hfail = !chol_g<G>(Hrow, hinvd, nv, c) && active;
+        if (__syncthreads_or(hfail)) {
+            // rare: rebuild with the PSD majorant for every group of the block (cheap, keeps barriers uniform)
+            const bool use_neg = !hfail;
+            build_H(use_neg);
+            hfail = !chol_g<G>(Hrow, hinvd, nv, c) && active;
+            if (hfail) active = false;
+        }
         float search_c = chol_solve_g<G>(Hrow, hinvd, -grad_c, nv, c, tile);
         if (!isdof) search_c = 0;
         __syncthreads();

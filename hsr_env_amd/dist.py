@@ -33,27 +33,33 @@ def unpack_step(packed):
     return packed[:, :-2], packed[:, -2], packed[:, -1] > 0.5
 
 
-def all_gather_step(packed_local, world: int, out=None):
-    """One all-gather of the packed step outputs; equal shard sizes (weak scaling) use the flat
-    all_gather_into_tensor, ragged shards fall back to all_gather with padding."""
+def all_gather_step(packed_local, world: int, out=None, equal_shards=None):
+    """One all-gather of the packed step outputs.  Equal shard sizes (the weak-scaling benchmark) use the flat
+    all_gather_into_tensor; ragged shards exchange sizes first and pad (pass equal_shards to skip the size exchange)."""
     import torch
     import torch.distributed as dist
     if world == 1 or not dist.is_initialized():
         return packed_local
-    n_local = torch.tensor([packed_local.shape[0]], device=packed_local.device)
-    sizes = [torch.zeros_like(n_local) for _ in range(world)]
-    if getattr(all_gather_step, "_equal", None) is None:
+    if equal_shards is None:
+        n_local = torch.tensor([packed_local.shape[0]], device=packed_local.device)
+        sizes = [torch.zeros_like(n_local) for _ in range(world)]
         dist.all_gather(sizes, n_local)
-        all_gather_step._sizes = [int(s.item()) for s in sizes]
-        all_gather_step._equal = len(set(all_gather_step._sizes)) == 1
-    if all_gather_step._equal:
+        sizes = [int(s.item()) for s in sizes]
+        equal_shards = len(set(sizes)) == 1
+    else:
+        sizes = [packed_local.shape[0]] * world
+    if equal_shards:
         if out is None:
             out = torch.empty((world * packed_local.shape[0], packed_local.shape[1]), dtype=packed_local.dtype, device=packed_local.device)
-        dist.all_gather_into_tensor(out, packed_local)
+        if dist.get_backend() == "gloo":
+            bufs = list(out.chunk(world, dim=0))
+            dist.all_gather(bufs, packed_local)
+        else:
+            dist.all_gather_into_tensor(out, packed_local)
         return out
-    mx = max(all_gather_step._sizes)
+    mx = max(sizes)
     pad = torch.zeros((mx, packed_local.shape[1]), dtype=packed_local.dtype, device=packed_local.device)
     pad[:packed_local.shape[0]] = packed_local
     bufs = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(bufs, pad)
-    return torch.cat([b[:n] for b, n in zip(bufs, all_gather_step._sizes)], dim=0)
+    return torch.cat([b[:n] for b, n in zip(bufs, sizes)], dim=0)

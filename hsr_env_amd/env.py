@@ -1,0 +1,248 @@
+"""Vectorised counterpart of ``hsr.env.HSREnv`` / ``hsr.mujoco_env.MujocoEnv`` (reference:
+hsr/env.py:23-209, hsr/mujoco_env.py:20-151): same constructor arguments, ``step / reset / seed /
+set_state``, spaces, goal-within-geofence reward with per-substep early exit - for N envs advanced in
+lockstep by libhsrsim (``BatchSim``).  With ``n_envs == 1`` every return value has the reference's scalar
+shapes, so the driver loop of hsr/control.py:66-76 runs against it unchanged.
+
+Semantics recorded in SURVEY.md section 8(a) "known reference defects": a goal is
+``GoalSpec(a=<body name>, b=<point or Box(3)>, distance)``: success = |xpos(a) - b| < distance with b
+written to ``mocap_pos`` at reset (the working shape of hsr/__init__.py:12); ``starts`` maps a joint name
+to a Box over its qpos slice, sampled per env at reset (hsr/env.py:149-156).
+"""
+from __future__ import annotations
+
+from collections import namedtuple
+from pathlib import Path
+from typing import Dict, List, Optional
+
+import numpy as np
+
+from .compiler import Model, load_config
+from .spaces import Box, Space
+
+GoalSpec = namedtuple("GoalSpec", "a b distance")     # hsr/env.py:20
+
+
+def distance_between(pos1, pos2):                        # hsr/env.py:231-232
+    return np.sqrt(np.sum(np.square(pos1 - pos2), axis=-1))
+
+
+def quaternion2euler(w, x, y, z):                        # hsr/env.py:212-228
+    ysqr = y * y
+    t0 = +2.0 * (w * x + y * z)
+    t1 = +1.0 - 2.0 * (x * x + ysqr)
+    euler_x = np.arctan2(t0, t1)
+    t2 = np.clip(+2.0 * (w * y - z * x), -1, 1)
+    euler_y = np.arcsin(t2)
+    t3 = +2.0 * (w * z + x * y)
+    t4 = +1.0 - 2.0 * (ysqr + z * z)
+    euler_z = np.arctan2(t3, t4)
+    return euler_x, euler_y, euler_z
+
+
+def mat2euler(mat):                                      # hsr/env.py:256-272
+    mat = np.asarray(mat, dtype=np.float64)
+    assert mat.shape[-2:] == (3, 3), "Invalid shape matrix {}".format(mat)
+    cy = np.sqrt(mat[..., 2, 2] * mat[..., 2, 2] + mat[..., 1, 2] * mat[..., 1, 2])
+    condition = cy > np.finfo(np.float64).eps * 4.
+    euler = np.empty(mat.shape[:-1], dtype=np.float64)
+    euler[..., 2] = np.where(condition, -np.arctan2(mat[..., 0, 1], mat[..., 0, 0]), -np.arctan2(-mat[..., 1, 0], mat[..., 1, 1]))
+    euler[..., 1] = np.where(condition, -np.arctan2(-mat[..., 0, 2], cy), -np.arctan2(-mat[..., 0, 2], cy))
+    euler[..., 0] = np.where(condition, -np.arctan2(mat[..., 1, 2], mat[..., 2, 2]), 0.0)
+    return euler
+
+
+def block_space_to_qpos(sample4: np.ndarray) -> np.ndarray:
+    """(x, y, z, yaw) of a block -> free-joint qpos (x y z qw qx qy qz); the build's reading of
+    ``--block-space`` (a Box(4), hsr/util.py:33), see SURVEY.md section 8(a) defects."""
+    s = np.asarray(sample4, dtype=np.float64)
+    out = np.zeros(s.shape[:-1] + (7,))
+    out[..., :3] = s[..., :3]
+    out[..., 3] = np.cos(s[..., 3] / 2)
+    out[..., 6] = np.sin(s[..., 3] / 2)
+    return out
+
+
+class VecHSREnv:
+    metadata = {"render.modes": "rgb_array"}
+
+    def __init__(self, xml_file=None, goals: Optional[List[GoalSpec]] = None, starts: Optional[Dict[str, Box]] = None,
+                 steps_per_action: int = 300, obs_type: str = None, render: bool = False, record: bool = False,
+                 record_freq: int = None, render_freq: int = None, record_path: Path = None,
+                 n_envs: int = 1, model: Optional[Model] = None, sim=None, device: int = 0,
+                 env_offset: int = 0, n_global: Optional[int] = None, block_space: Optional[Box] = None):
+        if model is None:
+            model = load_config(str(xml_file)) if xml_file is not None else None
+        if model is None:
+            raise IOError("File %s does not exist" % xml_file)          # hsr/mujoco_env.py:30-31
+        if any([render, record, record_path, record_freq and False]):
+            raise NotImplementedError("rendering / recording are outside the batched hot path (camera-free obs)")
+        if obs_type == "openai":
+            raise NotImplementedError("the 'openai' observation branch of the reference is dead code (SURVEY.md 8a-5)")
+        self.model = model
+        self.n_envs = int(n_envs)
+        self.env_offset, self.n_global = int(env_offset), int(n_global or n_envs)
+        self.starts = dict(starts or {})
+        self.block_space = block_space
+        self.goals_specs = goals
+        self.goals = None
+        self._time_steps = np.zeros(self.n_envs, dtype=np.int64)
+        self._obs_type = obs_type
+        self.reward_range = -np.inf, np.inf
+        self.spec = None
+        self.steps_per_action = steps_per_action
+        self.record_freq = record_freq or 20
+        self.render_freq = render_freq or 20
+        self.frame_skip = self.record_freq                              # hsr/env.py:68 passes record_freq
+        self._block_name = "block0"
+        self._finger_names = ["hand_l_distal_link", "hand_r_distal_link"]
+        if sim is None:
+            from .sim import BatchSim
+            sim = BatchSim(model, self.n_envs, device=device)
+        self.sim = sim
+        bounds = model.act_ctrlrange.copy()
+        self.action_space = Box(low=bounds[:, 0], high=bounds[:, 1], dtype=np.float32)
+        self.init_qpos = model.qpos0.copy()
+        self.init_qvel = np.zeros(model.nv)
+        self.obs_dim = model.nq + model.nv
+        high = np.inf * np.ones(self.obs_dim)
+        self.observation_space = Box(-high, high, dtype=np.float32)
+        self._goal_body, self._geofence = -1, 0.0
+        self._goal_points = np.zeros((self.n_envs, 3), dtype=np.float32)
+        self._parse_goals()
+        self.seed()
+        t, q, v = self.sim.get_state()
+        self.initial_state = (t.copy(), q.copy(), v.copy())
+        self._last_obs = np.concatenate([q, v], axis=1)
+
+    # ------------------------------------------------------------------ helpers
+    def _squeeze(self, x):
+        return x[0] if self.n_envs == 1 else x
+
+    def _parse_goals(self):
+        if not self.goals_specs:
+            return
+        if len(self.goals_specs) != 1:
+            raise NotImplementedError("the device goal test supports one GoalSpec (the reference CLI builds exactly one, hsr/util.py:70-74)")
+        a, b, d = self.goals_specs[0]
+        if not isinstance(a, str):
+            raise RuntimeError(f"{a} must be function, np.ndarray, or string")   # hsr/env.py:145 (only names run on device)
+        self._goal_body = self.model.body_id(a)
+        self._geofence = float(d)
+
+    @property
+    def dt(self):
+        return self.model.timestep * self.frame_skip                   # hsr/mujoco_env.py:96-98
+
+    def seed(self, seed=None):
+        self._seed = 0 if seed is None else int(seed)
+        self._reset_count = 0
+        self.np_random = np.random.Generator(np.random.Philox(key=self._seed))
+        return [seed]
+
+    def _global_rng(self):
+        # one stream per (seed, reset index); every rank draws the global batch and keeps its shard, so a
+        # sharded run reproduces the single-GPU run env for env
+        return np.random.Generator(np.random.Philox(key=[self._seed, self._reset_count]))
+
+    def _shard(self, x):
+        return x[self.env_offset:self.env_offset + self.n_envs]
+
+    # ------------------------------------------------------------------ gym surface
+    def new_state(self, rng=None):
+        """hsr/env.py:149-156: qpos with every joint in ``starts`` resampled (per env)."""
+        rng = rng or self._global_rng()
+        qpos = np.tile(self.model.qpos0, (self.n_global, 1))
+        for joint, space in self.starts.items():
+            assert isinstance(space, Space)
+            adr = self.model.joint_qpos_addr(joint)
+            start, end = adr if isinstance(adr, tuple) else (adr, adr + 1)
+            qpos[:, start:end] = space.sample(self.n_global, rng=rng)
+        if self.block_space is not None:
+            nb = (self.model.nq - self.model.nu) // 7
+            for b in range(nb):
+                a = self.model.nu + 7 * b
+                qpos[:, a:a + 7] = block_space_to_qpos(self.block_space.sample(self.n_global, rng=rng))
+        return self._shard(qpos)
+
+    def reset(self, mask=None):
+        """sim.reset() + reset_model() (hsr/mujoco_env.py:83-85, hsr/env.py:158-177); ``mask`` selects envs."""
+        rng = self._global_rng()
+        self._reset_count += 1
+        m = np.ones(self.n_envs, dtype=bool) if mask is None else np.asarray(mask, dtype=bool).reshape(self.n_envs)
+        self._time_steps[m] = 0
+        if self.goals_specs:
+            a, b, d = self.goals_specs[0]
+            pts = b.sample(self.n_global, rng=rng) if isinstance(b, Space) else np.tile(np.asarray(b, dtype=np.float32), (self.n_global, 1))
+            pts = self._shard(np.asarray(pts, dtype=np.float32).reshape(self.n_global, 3))
+            self._goal_points[m] = pts[m]
+            self.goals = [GoalSpec(a, self._squeeze(self._goal_points), d)]
+        qpos = self.new_state(rng).astype(np.float32)
+        self.sim.reset(mask=m.astype(np.uint8), qpos0=qpos, mocap=self._goal_points)
+        return self._get_observation()
+
+    def set_state(self, qpos, qvel):
+        qpos = np.asarray(qpos, dtype=np.float32).reshape(self.n_envs, -1)
+        qvel = np.asarray(qvel, dtype=np.float32).reshape(self.n_envs, -1)
+        assert qpos.shape[1:] == (self.model.nq,) and qvel.shape[1:] == (self.model.nv,)   # hsr/mujoco_env.py:88-89
+        t = self.sim.get_state()[0]
+        self.sim.set_state(t, qpos, qvel)
+
+    def state_vector(self):
+        return self._get_observation()
+
+    def _get_observation(self):
+        t, q, v = self.sim.get_state()
+        self._last_obs = np.concatenate([q, v], axis=1)                 # hsr/env.py:111-113
+        return self._squeeze(self._last_obs)
+
+    def step(self, action, steps=None):
+        """hsr/env.py:115-135 for every env: returns (obs, reward, done, info)."""
+        action = np.asarray(action, dtype=np.float32).reshape(self.n_envs, self.model.nu)
+        steps = steps or self.steps_per_action
+        goal_body = self._goal_body if self.goals else -1
+        obs, rew, done, ns = self.sim.step(action, steps, goal_body, self._geofence)
+        self._time_steps += 1
+        self._last_obs = obs
+        success = done
+        info = {"log count": {"success": self._squeeze(success & (self._time_steps > 0))}, "substeps": self._squeeze(ns)}
+        if self.n_envs == 1:
+            return obs[0], float(rew[0]), bool(done[0]), info
+        return obs, rew, done, info
+
+    def in_range(self, a, b, distance):
+        def parse(x):
+            if callable(x):
+                return x()
+            if isinstance(x, np.ndarray):
+                return x
+            if isinstance(x, str):
+                return self._squeeze(self.sim.body_xpos(self.model.body_id(x)))
+            raise RuntimeError(f"{x} must be function, np.ndarray, or string")
+        return distance_between(parse(a), parse(b)) < distance
+
+    def block_pos(self):
+        return self._squeeze(self.sim.body_xpos(self.model.body_id(self._block_name)))
+
+    def gripper_pos(self):
+        f1, f2 = [self.sim.body_xpos(self.model.body_id(n)) for n in self._finger_names]
+        return self._squeeze((f1 + f2) / 2.)
+
+    def get_body_com(self, body_name):
+        return self._squeeze(self.sim.body_xpos(self.model.body_id(body_name)))
+
+    def render(self, *a, **k):
+        raise NotImplementedError("camera-free observations only (SURVEY.md section 2, #2)")
+
+    def close(self):
+        if getattr(self.sim, "close", None):
+            self.sim.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *args):
+        self.close()
+
+
+HSREnv = VecHSREnv

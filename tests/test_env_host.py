@@ -1,0 +1,127 @@
+"""Host-side mirror of HSREnv / MujocoEnv (hsr/env.py, hsr/mujoco_env.py) exercised on CPU through the
+oracle-backed stand-in of BatchSim (tests/oracle_batch.py)."""
+import numpy as np
+import pytest
+
+from hsr_env_amd import GoalSpec, VecHSREnv, Box
+from hsr_env_amd import util
+from hsr_env_amd.env import block_space_to_qpos, mat2euler, quaternion2euler, distance_between
+from oracle_batch import OracleBatchSim
+
+
+def make_env(models, cfg="cfg2", n=1, **kw):
+    m = models[cfg]
+    return VecHSREnv(model=m, n_envs=n, sim=OracleBatchSim(m, n), **kw)
+
+
+def test_single_env_contract_matches_reference_shapes(models):
+    """N = 1: obs[nq+nv], float reward, bool done, info keys of hsr/env.py:133-135; control.py loop runs."""
+    env = make_env(models, "cfg1", 1, goals=None, starts={}, steps_per_action=5)
+    assert env.action_space.shape == (2,) and np.allclose(env.action_space.low, [-1, -1])    # world.xml:106,109
+    assert env.observation_space.shape == (4,) and env.obs_dim == 4
+    done = False
+    for _ in range(3):                                   # hsr/control.py:73-76
+        if done:
+            env.reset()
+        s, r, t, i = env.step(np.zeros(2))
+        done = t
+        assert s.shape == (4,) and isinstance(r, float) and isinstance(t, bool)
+        assert set(i["log count"]) == {"success"}
+    assert not done                                        # goals is None -> done stays False (hsr/env.py:125)
+    assert abs(env.dt - 0.002 * 20) < 1e-12               # frame_skip = record_freq default 20 (hsr/env.py:54,68)
+
+
+def test_goal_reset_and_early_exit(models):
+    m = models["cfg2"]
+    goal_space = Box(low=[-.1, -.2, .422], high=[.1, .2, .422])
+    block_space = Box(low=[-.1, -.2, .422, -3.14], high=[.1, .2, .422, 3.14])
+    env = make_env(models, "cfg2", 8, goals=[GoalSpec("block0", goal_space, 0.5)], block_space=block_space, steps_per_action=30)
+    env.seed(3)
+    obs = env.reset()
+    assert obs.shape == (8, 17)
+    # block pose was sampled from block_space, goal from goal_space and written to mocap_pos (hsr/env.py:169)
+    assert (np.abs(obs[:, 2]) <= .1).all() and np.allclose(obs[:, 4], .422) and np.allclose(np.linalg.norm(obs[:, 5:9], axis=1), 1)
+    assert np.allclose(env.sim.body_xpos(m.body_id("goal")), env._goal_points)
+    # geofence .5 covers the whole pan: success at the first substep, obs is the state at that substep
+    obs, rew, done, info = env.step(np.zeros((8, 2)))
+    assert done.all() and (rew == 1).all() and (info["substeps"] == 1).all()
+    assert env.in_range("block0", env._goal_points, 0.5).all()
+    env2 = make_env(models, "cfg2", 8, goals=[GoalSpec("block0", np.array([.4, 0, .422]), 0.05)], steps_per_action=30)
+    env2.reset()
+    obs, rew, done, info = env2.step(np.zeros((8, 2)))
+    assert (not done.any()) and (info["substeps"] == 30).all()
+
+
+def test_starts_sample_joint_slices(models):
+    """hsr/__init__.py:14-18: starts={'blockjoint': Box(7)} resamples that joint's qpos slice at reset."""
+    m = models["cfg2"]
+    box = Box(low=[-.1, -.2, .43, 1, 0, 0, 0], high=[.1, .2, .43, 1, 0, 0, 0])
+    env = make_env(models, "cfg2", 4, goals=[GoalSpec("block0", np.array([0, 0, .498]), .05)], starts={"block0joint": box})
+    obs = env.reset()
+    assert np.allclose(obs[:, 4], .43) and np.allclose(obs[:, 5:9], [1, 0, 0, 0]) and np.ptp(obs[:, 2]) > 0
+    assert np.allclose(env.block_pos(), obs[:, 2:5], atol=1e-6)
+    g = env.gripper_pos()
+    assert g.shape == (4, 3)
+
+
+def test_masked_reset_keeps_other_envs(models):
+    env = make_env(models, "cfg2", 4, goals=None, steps_per_action=10)
+    env.reset()
+    env.step(np.ones((4, 2)))
+    before = env._get_observation().copy()
+    env.reset(mask=[True, False, True, False])
+    after = env._get_observation()
+    assert np.array_equal(after[[1, 3]], before[[1, 3]]) and np.allclose(after[[0, 2], :2], 0)
+
+
+def test_sharded_sampling_reproduces_single_process(models):
+    """Rank r of W draws the global batch and keeps [r*N/W, (r+1)*N/W): shards concatenate to the 1-GPU run."""
+    m = models["cfg2"]
+    gs = Box(low=[-.1, -.2, .422], high=[.1, .2, .422]); bs = Box(low=[-.1, -.2, .422, -3], high=[.1, .2, .422, 3])
+    full = VecHSREnv(model=m, n_envs=6, sim=OracleBatchSim(m, 6), goals=[GoalSpec("block0", gs, .05)], block_space=bs)
+    full.seed(7); o_full = full.reset()
+    parts = []
+    for r in range(2):
+        e = VecHSREnv(model=m, n_envs=3, sim=OracleBatchSim(m, 3), goals=[GoalSpec("block0", gs, .05)], block_space=bs,
+                      env_offset=3 * r, n_global=6)
+        e.seed(7); parts.append((e.reset(), e._goal_points.copy()))
+    assert np.array_equal(np.concatenate([p[0] for p in parts]), o_full)
+    assert np.array_equal(np.concatenate([p[1] for p in parts]), full._goal_points)
+
+
+def test_set_state_shape_assertion(models):
+    env = make_env(models, "cfg1", 1)
+    with pytest.raises(AssertionError):
+        env.set_state(np.zeros(3), np.zeros(2))           # hsr/mujoco_env.py:88-89
+    env.set_state(np.array([.05, -.02]), np.zeros(2))
+    assert np.allclose(env._get_observation()[:2], [.05, -.02])
+
+
+def test_bad_goal_type_raises(models):
+    with pytest.raises(RuntimeError):
+        make_env(models, "cfg2", 1, goals=[GoalSpec(3.0, np.zeros(3), .1)])      # hsr/env.py:145
+
+
+def test_cli_grammar():
+    """rl_utils/argparse.py:62-73 space grammar and the reference's flag names (hsr/util.py:16-40)."""
+    import argparse
+    b = util.parse_space(3)("(-.1,.1)(-.2,.2)(.422,.422)")
+    assert np.allclose(b.low, [-.1, -.2, .422]) and np.allclose(b.high, [.1, .2, .422])
+    with pytest.raises(argparse.ArgumentTypeError):
+        util.parse_space(4)("(0,1)(0,1)")
+    parser = argparse.ArgumentParser()
+    util.add_env_args(parser.add_argument_group("env_args")); util.add_wrapper_args(parser.add_argument_group("wrapper_args"))
+    args = util.hierarchical_parse_args(parser, ["--steps-per-action=300", "--geofence=.5", "--goal-space", "(0,0)(0,0)(0,0)",
+                                                 "--use-dof", "slide_x", "--use-dof", "slide_y"])
+    assert args["env_args"]["steps_per_action"] == 300 and args["wrapper_args"]["use_dof"] == ["slide_x", "slide_y"]
+    assert args["wrapper_args"]["n_blocks"] == 0 and args["wrapper_args"]["geofence"] == .5
+    m = util.model_for(["slide_y", "slide_x"], 1)
+    assert (m.nq, m.nv, m.nu) == (9, 8, 2)
+
+
+def test_math_helpers():
+    assert np.allclose(block_space_to_qpos(np.array([.1, .2, .3, np.pi / 2])), [.1, .2, .3, np.cos(np.pi / 4), 0, 0, np.sin(np.pi / 4)])
+    assert np.allclose(quaternion2euler(np.cos(.2), 0, 0, np.sin(.2)), (0, 0, .4))
+    c, s = np.cos(.3), np.sin(.3)
+    assert np.allclose(mat2euler(np.array([[c, -s, 0], [s, c, 0], [0, 0, 1]])), [0, 0, .3])
+    assert distance_between(np.zeros(3), np.array([3., 4, 0])) == 5
