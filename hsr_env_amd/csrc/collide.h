@@ -7,13 +7,20 @@
 #include "model.h"
 
 // ------------------------------------------------------------------ kinematics (a-2.1)
-__global__ void k_kinematics(DevModel m, DevState s) {
-    int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= s.N) return;
-    if (s.done[e]) return;
-    const int N = s.N;
-    View qpos{s.qpos + e, N}, xpos{s.xpos + e, N}, xmat{s.xmat + e, N};
-    View ang{s.dof_ang + e, N}, lin{s.dof_lin + e, N}, anc{s.dof_anchor + e, N};
+__global__ void __launch_bounds__(64) k_kinematics(DevModel m, DevState s) {
+    // The solver's inputs (dof axes, per-link wrenches) are produced per lane in an LDS tile [64][kstride+1] and
+    // written out env-major with coalesced stores, so that the solver's 16-lane groups read whole 256-B lines
+    // instead of 4-byte pieces of 64 different lines.
+    extern __shared__ float ktile[];
+    const int e_raw = blockIdx.x * 64 + threadIdx.x;
+    const bool live = e_raw < s.N && !s.done[e_raw < s.N ? e_raw : 0];
+    const int e = live ? e_raw : 0;
+    // per-lane LDS record: [kstride: solver inputs | 3 nlink xpos | 9 nlink xmat | 12 nlink link velocity state] (+1 pad)
+    const int N = s.N, TS = s.kstride + 24 * m.nlink + 1;
+    float *tl = ktile + threadIdx.x * TS;
+    if (live) {
+    View qpos{s.qpos + e, N}, xpos{tl + s.kstride, 1}, xmat{tl + s.kstride + 3 * m.nlink, 1};
+    View ang{tl, 1}, lin{tl + 3 * m.nv, 1}, anc{tl + 6 * m.nv, 1};
     m3 I;
 #pragma unroll
     for (int k = 0; k < 9; k++) I.a[k] = (k % 4 == 0) ? 1.f : 0.f;
@@ -74,8 +81,8 @@ __global__ void k_kinematics(DevModel m, DevState s) {
     }
     // ---- link velocities / bias accelerations (qacc = 0) and the per-link wrench of mj_rne:
     //      F = m (a_com - g), N = I alpha + w x I w  (consumed by the solve kernel as bias = J^T [F; N])
-    View qvel{s.qvel + e, N}, ws{s.ws + e, N}, ld{s.link_dyn + e, N};
-    View lw = ws.sub(s.o_lw), lvo = ws.sub(s.o_lvo), lal = ws.sub(s.o_lal), lao = ws.sub(s.o_lao);
+    View qvel{s.qvel + e, N}, ld{tl + 9 * m.nv, 1};
+    View lw{tl + s.kstride + 12 * m.nlink, 1}, lvo{tl + s.kstride + 15 * m.nlink, 1}, lal{tl + s.kstride + 18 * m.nlink, 1}, lao{tl + s.kstride + 21 * m.nlink, 1};
     lw.set3(0, mk3(0, 0, 0)); lvo.set3(0, mk3(0, 0, 0)); lal.set3(0, mk3(0, 0, 0)); lao.set3(0, mk3(0, 0, 0));
     for (int k = 0; k < 15; k++) ld[k] = 0;
     for (int l = 1; l < m.nlink; l++) {
@@ -129,6 +136,26 @@ __global__ void k_kinematics(DevModel m, DevState s) {
         ld[b] = com.x; ld[b + 1] = com.y; ld[b + 2] = com.z;
         ld[b + 3] = I.a[0]; ld[b + 4] = I.a[4]; ld[b + 5] = I.a[8]; ld[b + 6] = I.a[1]; ld[b + 7] = I.a[2]; ld[b + 8] = I.a[5];
         ld[b + 9] = F.x; ld[b + 10] = F.y; ld[b + 11] = F.z; ld[b + 12] = Nt.x; ld[b + 13] = Nt.y; ld[b + 14] = Nt.z;
+    }
+    for (int i = 9 * m.nv + 15 * m.nlink; i < s.kstride; i++) tl[i] = 0.f;
+    }
+    __syncthreads();
+    // coalesced env-major write of the 64 records of this workgroup
+    const int e0 = blockIdx.x * 64, KS = s.kstride;
+    const unsigned long long livemask = __ballot(live);
+    for (int le = 0; le < 64; le++) {
+        if (!((livemask >> le) & 1ull)) continue;
+        float *dst = s.kin_aos + (size_t)(e0 + le) * KS;
+        const float *src = ktile + le * TS;
+        for (int i = threadIdx.x; i < KS; i += 64) dst[i] = src[i];
+    }
+    if (live) {   // link poses for k_collide / body_xpos: struct-of-arrays, one coalesced store per row
+        for (int i = 0; i < 3 * m.nlink; i++) s.xpos[(size_t)i * N + e] = tl[s.kstride + i];
+        for (int i = 0; i < 9 * m.nlink; i++) s.xmat[(size_t)i * N + e] = tl[s.kstride + 3 * m.nlink + i];
+    }
+    if (s.want_soa_kin && live) {   // only the one-lane-per-env fallback solver reads the struct-of-arrays copies
+        for (int i = 0; i < 3 * m.nv; i++) { s.dof_ang[(size_t)i * N + e] = tl[i]; s.dof_lin[(size_t)i * N + e] = tl[3 * m.nv + i]; s.dof_anchor[(size_t)i * N + e] = tl[6 * m.nv + i]; }
+        for (int i = 0; i < 15 * m.nlink; i++) s.link_dyn[(size_t)i * N + e] = tl[9 * m.nv + i];
     }
 }
 

@@ -391,6 +391,8 @@ extern "C" int hsr_batch_create(const hsr_model *m, int n_envs, int device_id, h
     DA(qpos, d.nq) DA(qvel, d.nv) DA(ctrl, d.nu) DA(mocap, 3) DA(warm, d.nv) DA(time, 1)
     DA(done, 1) DA(bad, 1) DA(nsteps, 1)
     DA(xpos, 3 * d.nlink) DA(xmat, 9 * d.nlink) DA(dof_ang, 3 * d.nv) DA(dof_lin, 3 * d.nv) DA(dof_anchor, 3 * d.nv) DA(link_dyn, 15 * d.nlink)
+    s.kstride = (9 * d.nv + 15 * d.nlink + 15) & ~15;
+    DA(kin_aos, s.kstride)
     DA(con, 8 * d.nslot) DA(ncon_pair, d.npair_pad)
     DA(M, d.nM) DA(qacc, d.nv) DA(qacc_smooth, d.nv) DA(qfrc_smooth, d.nv) DA(qfrc_constraint, d.nv)
     DA(ncon, 1) DA(nefc, 1) DA(niter, 1)
@@ -422,13 +424,19 @@ extern "C" int hsr_batch_create(const hsr_model *m, int n_envs, int device_id, h
         b->solver = (sv && strcmp(sv, "v1") == 0) ? 0 : 1;
         if (d.nv > 32 || d.nlink > NLMAX || d.nconmax > b->group) b->solver = 0;
         const int total = b->group == 16 ? SolveLayout<16>(d.njmax).total : SolveLayout<32>(d.njmax).total;
-        if (!(b->group == 16 ? SolveLayout<16>(d.njmax).fits() : SolveLayout<32>(d.njmax).fits())) b->solver = 0;
+        if (!(b->group == 16 ? SolveLayout<16>(d.njmax).fits(b->ds.kstride) : SolveLayout<32>(d.njmax).fits(b->ds.kstride)) || b->ds.kstride > 8 * 4 * b->group) b->solver = 0;
         b->group_lds_bytes = (size_t)total * (64 / b->group) * sizeof(float);
         if (b->group_lds_bytes > 160 * 1024) b->solver = 0;
         if (b->solver && b->group_lds_bytes > 48 * 1024) {
             if (b->group == 16) HIPCHK(hipFuncSetAttribute((const void *)k_solve_g<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->group_lds_bytes));
             else HIPCHK(hipFuncSetAttribute((const void *)k_solve_g<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->group_lds_bytes));
         }
+    }
+    b->ds.want_soa_kin = b->solver == 0 ? 1 : 0;
+    {
+        const size_t kb = (size_t)64 * (b->ds.kstride + 24 * d.nlink + 1) * sizeof(float);
+        if (kb > 160 * 1024) return fail(HSR_EINVAL, "kinematics tile exceeds LDS");
+        if (kb > 48 * 1024) HIPCHK(hipFuncSetAttribute((const void *)k_kinematics, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kb));
     }
     b->stage_floats = N * (size_t)(std::max(std::max(d.nq + d.nv, 7 * d.nslot), std::max(d.nv * d.nv, 9 * d.nlink)) + d.nu + d.nq + d.nv + 4) + 16;
     if ((rc = dalloc(b, &b->d_stage, b->stage_floats))) return rc;
@@ -470,7 +478,7 @@ static void launch_substep(hsr_batch *b, int mode, int goal_body, float geofence
     const int N = b->N;
     auto rec = [&](void) { if (timed) { hipEvent_t ev; hipEventCreate(&ev); hipEventRecord(ev, st); b->kev.push_back(ev); } };
     rec();
-    hipLaunchKernelGGL(k_kinematics, dim3((N + 63) / 64), dim3(64), 0, st, b->dm, b->ds);
+    hipLaunchKernelGGL(k_kinematics, dim3((N + 63) / 64), dim3(64), (size_t)64 * (b->ds.kstride + 24 * b->dm.nlink + 1) * sizeof(float), st, b->dm, b->ds);
     rec();
     if (b->dm.npair > 0) hipLaunchKernelGGL(k_collide, dim3((N + 63) / 64, (b->dm.npair + b->pairs_per_wave - 1) / b->pairs_per_wave), dim3(64), 0, st, b->dm, b->ds);
     rec();

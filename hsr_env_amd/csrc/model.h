@@ -40,6 +40,9 @@ struct DevState {
     float *xpos, *xmat, *dof_ang, *dof_lin, *dof_anchor;
     // per-link dynamics terms from the kinematics kernel: com(3) Iworld(6: xx yy zz xy xz yz) F(3) N(3)
     float *link_dyn;
+    // env-major copy of the solver's kinematic inputs: kin_aos[e][kstride] = ang[3nv] lin[3nv] anchor[3nv] link_dyn[15 nlink]
+    float *kin_aos;
+    int kstride, want_soa_kin;
     // collision outputs, env-major so that one env's lane group reads them coalesced:
     //   con[(e * nslot + slot) * 8 + k]  (pos 0-2, normal 3-5, dist 6), ncon_pair[e * npair_pad + p]
     float *con;

@@ -163,7 +163,7 @@ template <int G> struct SolveLayout {
         R = rows; RS = G + 4; MS = G + 1;
         int o = 0;
         oJ = o;
-        oAng = o; oLin = oAng + 3 * G; oAnc = oLin + 3 * G; oLk = oAnc + 3 * G;       // 9G + 15*NLMAX <= R*RS (checked on host)
+        oAng = o; oLin = 0; oAnc = 0; oLk = 0;       // flat copy of the env's kin_aos record (kstride floats <= R*RS, checked on host)
         o += R * RS;
         oD = o; o += R; oAref = o; o += R; oJar = o; o += R; oJv = o; o += R; oGr = o; o += R; oDw = o; o += R;
         oVec = o; o += NVEC * G;
@@ -171,7 +171,7 @@ template <int G> struct SolveLayout {
         oCon = o; o += CR_SIZE * G;
         total = (o + 3) & ~3;
     }
-    __host__ __device__ bool fits() const { return 9 * G + 15 * NLMAX <= R * RS; }
+    __host__ __device__ bool fits(int kstride) const { return kstride <= R * RS; }
 };
 
 template <int G>
@@ -189,7 +189,8 @@ __global__ void __launch_bounds__(64) k_solve_g(DevModel m, DevState s, int mode
     float *J = E + L.oJ, *rD = E + L.oD, *rAref = E + L.oAref, *rJar = E + L.oJar, *rJv = E + L.oJv, *rGr = E + L.oGr, *rDw = E + L.oDw;
     float *vQvel = E + L.oVec, *vQfs = vQvel + G, *vQas = vQfs + G, *vQacc = vQas + G, *vMa = vQacc + G, *vSearch = vMa + G,
           *vWarm = vSearch + G, *vQfc = vWarm + G;
-    float *M = E + L.oM, *tile = E + L.oTile, *kAng = E + L.oAng, *kLin = E + L.oLin, *kAnc = E + L.oAnc, *lk = E + L.oLk, *con = E + L.oCon;
+    float *M = E + L.oM, *tile = E + L.oTile, *con = E + L.oCon;
+    float *kAng = E + L.oAng, *kLin = kAng + 3 * nv, *kAnc = kAng + 6 * nv, *lk = kAng + 9 * nv;     // layout of kin_aos
     const bool isdof = c < nv;
     int bad = 0;
     // model constants used inside loops: one copy per workgroup in LDS (no dependent global loads later)
@@ -218,8 +219,6 @@ __global__ void __launch_bounds__(64) k_solve_g(DevModel m, DevState s, int mode
         my_quat_lane = m.link_dofadr[m.dof_link[c]] + 3;
         damp_c = m.dof_damping[c];
         qvel_c = s.qvel[(size_t)c * N + e]; warm_c = s.warm[(size_t)c * N + e];
-        View ang{s.dof_ang + e, N}, lin{s.dof_lin + e, N}, anc{s.dof_anchor + e, N};
-        a_c = ang.get3(c); l_c = lin.get3(c); n_c = anc.get3(c);
         lim_lo = m.dof_range[2 * c]; lim_hi = m.dof_range[2 * c + 1]; lim_sr0 = m.dof_solref[2 * c]; lim_sr1 = m.dof_solref[2 * c + 1];
         lim_iw = m.dof_invweight0[c];
 #pragma unroll
@@ -233,20 +232,25 @@ __global__ void __launch_bounds__(64) k_solve_g(DevModel m, DevState s, int mode
         }
         if (!(fabsf(qvel_c) <= 1e10f) || !(fabsf(my_q) <= 1e10f)) bad = 1;
     }
-    float lkreg[15];
+    {   // the env's kinematic record: kstride floats, env-major, copied with 16-byte loads (256 B per group instruction)
+        const float4 *src = reinterpret_cast<const float4 *>(s.kin_aos + (size_t)e * s.kstride);
+        float4 *dst = reinterpret_cast<float4 *>(kAng);
+        const int n4 = s.kstride / 4;
+        float4 tmp[8];
 #pragma unroll
-    for (int k = 0; k < 15; k++) lkreg[k] = (c < m.nlink && c < NLMAX) ? s.link_dyn[(size_t)(15 * c + k) * N + e] : 0.f;
-    vQvel[c] = qvel_c; vWarm[c] = warm_c;
-    kAng[3 * c] = a_c.x; kAng[3 * c + 1] = a_c.y; kAng[3 * c + 2] = a_c.z;
-    kLin[3 * c] = l_c.x; kLin[3 * c + 1] = l_c.y; kLin[3 * c + 2] = l_c.z;
-    kAnc[3 * c] = n_c.x; kAnc[3 * c + 1] = n_c.y; kAnc[3 * c + 2] = n_c.z;
-    if (c < NLMAX) {
+        for (int i = 0; i < 8; i++) { const int idx = c + i * G; tmp[i] = idx < n4 ? src[idx] : make_float4(0, 0, 0, 0); }
 #pragma unroll
-        for (int k = 0; k < 15; k++) lk[15 * c + k] = lkreg[k];
+        for (int i = 0; i < 8; i++) { const int idx = c + i * G; if (idx < n4) dst[idx] = tmp[i]; }
     }
+    vQvel[c] = qvel_c; vWarm[c] = warm_c;
 #pragma unroll
     for (int k = 0; k < G + 1; k++) M[c * MS + k] = 0.f;
     __syncthreads();
+    if (isdof) {
+        a_c = mk3(kAng[3 * c], kAng[3 * c + 1], kAng[3 * c + 2]);
+        l_c = mk3(kLin[3 * c], kLin[3 * c + 1], kLin[3 * c + 2]);
+        n_c = mk3(kAnc[3 * c], kAnc[3 * c + 1], kAnc[3 * c + 2]);
+    }
 
     PHASE(0);
     // ---------------- phase B/C: inertia rows (a-2.2) and bias force (a-2.5), lane = dof
