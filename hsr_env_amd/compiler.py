@@ -334,7 +334,7 @@ _ARRAY_FIELDS = [
 
 # index constants into ``sizes`` / ``opt`` (mirrored in include/hsrsim.h and oracle/hsr_oracle.c)
 SZ_NQ, SZ_NV, SZ_NU, SZ_NLINK, SZ_NBODY, SZ_NGEOM, SZ_NPAIR, SZ_NMESHVERT, SZ_NSLOT, \
-    SZ_NLIMIT, SZ_NCONMAX, SZ_NJMAX, SZ_NMOCAP = range(13)
+    SZ_NLIMIT, SZ_NCONMAX, SZ_NJMAX, SZ_NMOCAP, SZ_NDENSE = range(14)
 OPT_TIMESTEP, OPT_IMPRATIO, OPT_GRAV_Z, OPT_TOLERANCE, OPT_ITERATIONS, OPT_LS_ITERATIONS, \
     OPT_LS_TOLERANCE, OPT_MPR_TOLERANCE, OPT_MPR_ITERATIONS, OPT_MEANINERTIA = range(10)
 
@@ -833,6 +833,22 @@ def compile_model(dofs: Sequence[str] = ("slide_x", "slide_y"), n_blocks: int = 
             a = link_dofadr[l]
             dinv[a:a + 3] = dinv[a:a + 3].mean(); dinv[a + 3:a + 6] = dinv[a + 3:a + 6].mean()
     arrays["dof_invweight0"][:] = dinv
+    # dofs >= ndense never couple to another dof in M (e.g. a free box with its COM at the body origin):
+    # the cooperative Cholesky skips their off-diagonal updates when factoring M and M + h B
+    rs = np.random.default_rng(0)
+    dense = 0
+    for _ in range(4):
+        qr = q0.copy()
+        qr[:len(acts)] += rs.uniform(-0.3, 0.3, len(acts))
+        for l in range(1, nlink):
+            if link_free[l]:
+                a = link_qposadr[l]
+                qr[a + 3:a + 7] = quat_normalize(rs.normal(size=4))
+        Mr = mass_matrix(model, qr)
+        off = np.abs(Mr - np.diag(np.diag(Mr))) > 1e-12
+        idx = np.where(off.any(axis=0))[0]
+        dense = max(dense, int(idx.max()) + 1 if idx.size else 0)
+    sizes[SZ_NDENSE] = dense
     xpos, xquat = link_kinematics(model, q0)
     ang, lin, anchor = dof_motion(model, xpos, xquat, q0)
     body_invw = np.zeros((nb, 2))

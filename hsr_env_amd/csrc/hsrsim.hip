@@ -18,6 +18,7 @@
 #include "model.h"
 #include "solve.h"
 #include "solve_g.h"
+#include "solve_mf.h"
 
 static thread_local char g_err[512] = "";
 static int fail(int code, const char *fmt, const char *detail = "") {
@@ -164,7 +165,7 @@ struct hsr_batch {
     int pairs_per_wave = 4;        // k_collide: pairs walked by one wave (HSR_PPW overrides)
     int solver = 1;                // 0: one lane per env (solve.h), 1: lane group per env (solve_g.h)
     int group = 16;
-    size_t group_lds_bytes = 0;
+    size_t group_lds_bytes = 0, mf_lds_bytes = 0;
     bool use_graph = true, profiling = false;
     std::map<GraphKey, hipGraphExec_t> graphs;
     float last_total_ms = 0, last_kernel_ms[3] = {0, 0, 0};
@@ -327,6 +328,7 @@ extern "C" int hsr_batch_create(const hsr_model *m, int n_envs, int device_id, h
     d.nq = sz[HSR_NQ]; d.nv = sz[HSR_NV]; d.nu = sz[HSR_NU]; d.nlink = sz[HSR_NLINK]; d.nbody = sz[HSR_NBODY];
     d.ngeom = sz[HSR_NGEOM]; d.npair = sz[HSR_NPAIR]; d.nslot = sz[HSR_NSLOT]; d.nconmax = sz[HSR_NCONMAX]; d.njmax = sz[HSR_NJMAX];
     d.nM = d.nv * (d.nv + 1) / 2;
+    d.ndense = sz[13];
     d.timestep = (float)m->opt[0]; d.impratio = (float)m->opt[1]; d.gravz = (float)m->opt[2]; d.tolerance = (float)m->opt[3];
     d.iterations = (int)m->opt[4]; d.ls_iterations = (int)m->opt[5]; d.ls_tolerance = (float)m->opt[6];
     d.mpr_tolerance = (float)m->opt[7]; d.mpr_iterations = (int)m->opt[8]; d.meaninertia = (float)m->opt[9];
@@ -421,7 +423,7 @@ extern "C" int hsr_batch_create(const hsr_model *m, int n_envs, int device_id, h
         const char *ppw = getenv("HSR_PPW");
         if (ppw && atoi(ppw) > 0) b->pairs_per_wave = atoi(ppw);
         const char *sv = getenv("HSR_SOLVER");
-        b->solver = (sv && strcmp(sv, "v1") == 0) ? 0 : 1;
+        b->solver = (sv && strcmp(sv, "v1") == 0) ? 0 : ((sv && strcmp(sv, "g") == 0) ? 1 : 2);   // default: matrix-free
         if (d.nv > 32 || d.nlink > NLMAX || d.nconmax > b->group) b->solver = 0;
         const int total = b->group == 16 ? SolveLayout<16>(d.njmax).total : SolveLayout<32>(d.njmax).total;
         if (!(b->group == 16 ? SolveLayout<16>(d.njmax).fits(b->ds.kstride) : SolveLayout<32>(d.njmax).fits(b->ds.kstride)) || b->ds.kstride > 8 * 4 * b->group) b->solver = 0;
@@ -430,6 +432,15 @@ extern "C" int hsr_batch_create(const hsr_model *m, int n_envs, int device_id, h
         if (b->solver && b->group_lds_bytes > 48 * 1024) {
             if (b->group == 16) HIPCHK(hipFuncSetAttribute((const void *)k_solve_g<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->group_lds_bytes));
             else HIPCHK(hipFuncSetAttribute((const void *)k_solve_g<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->group_lds_bytes));
+        }
+    }
+    if (b->solver == 2) {
+        const int total = b->group == 16 ? MfLayout<16>(d.njmax, b->ds.kstride).total : MfLayout<32>(d.njmax, b->ds.kstride).total;
+        b->mf_lds_bytes = (size_t)total * (64 / b->group) * sizeof(float);
+        if (b->ds.kstride > 8 * 4 * b->group || b->mf_lds_bytes > 160 * 1024) b->solver = 1;
+        else if (b->mf_lds_bytes > 48 * 1024) {
+            if (b->group == 16) HIPCHK(hipFuncSetAttribute((const void *)k_solve_mf<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->mf_lds_bytes));
+            else HIPCHK(hipFuncSetAttribute((const void *)k_solve_mf<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->mf_lds_bytes));
         }
     }
     b->ds.want_soa_kin = b->solver == 0 ? 1 : 0;
@@ -483,6 +494,8 @@ static void launch_substep(hsr_batch *b, int mode, int goal_body, float geofence
     if (b->dm.npair > 0) hipLaunchKernelGGL(k_collide, dim3((N + 63) / 64, (b->dm.npair + b->pairs_per_wave - 1) / b->pairs_per_wave), dim3(64), 0, st, b->dm, b->ds);
     rec();
     if (b->solver == 0) hipLaunchKernelGGL(k_solve, dim3((N + 63) / 64), dim3(64), b->hot_lds_bytes, st, b->dm, b->ds, mode, goal_body, geofence, debug);
+    else if (b->solver == 2 && b->group == 16) hipLaunchKernelGGL(k_solve_mf<16>, dim3((N + 3) / 4), dim3(64), b->mf_lds_bytes, st, b->dm, b->ds, mode, goal_body, geofence, debug);
+    else if (b->solver == 2) hipLaunchKernelGGL(k_solve_mf<32>, dim3((N + 1) / 2), dim3(64), b->mf_lds_bytes, st, b->dm, b->ds, mode, goal_body, geofence, debug);
     else if (b->group == 16) hipLaunchKernelGGL(k_solve_g<16>, dim3((N + 3) / 4), dim3(64), b->group_lds_bytes, st, b->dm, b->ds, mode, goal_body, geofence, debug);
     else hipLaunchKernelGGL(k_solve_g<32>, dim3((N + 1) / 2), dim3(64), b->group_lds_bytes, st, b->dm, b->ds, mode, goal_body, geofence, debug);
     rec();

@@ -9,7 +9,7 @@ enum { FN_PLANE_BOX = 0, FN_PLANE_CONVEX = 1, FN_BOX_BOX = 2, FN_CONVEX = 3 };
 
 // constant tables (device pointers; fp64 blob values converted to fp32 once at load)
 struct DevModel {
-    int nq, nv, nu, nlink, nbody, ngeom, npair, nslot, nconmax, njmax, nM;
+    int nq, nv, nu, nlink, nbody, ngeom, npair, nslot, nconmax, njmax, nM, ndense;
     float timestep, impratio, gravz, tolerance, ls_tolerance, mpr_tolerance, meaninertia;
     int iterations, ls_iterations, mpr_iterations, any_damping;
     const int *link_parent, *link_dofadr, *link_dofnum, *link_qposadr, *link_free;

@@ -16,11 +16,22 @@
 #include <type_traits>
 
 #ifdef HSR_PHASE_TIMING
-#define PHASE_T0() unsigned long long t_prev_ = __builtin_amdgcn_s_memtime(); int ph_ = 0
-#define PHASE(idx) do { unsigned long long t_now_ = __builtin_amdgcn_s_memtime(); if (tid == 0) atomicAdd(&s.phase_cyc[idx], t_now_ - t_prev_); t_prev_ = __builtin_amdgcn_s_memtime(); (void)ph_; } while (0)
+// diagnostic build only: stamp = one asm statement (s_memtime + its wait) fenced by sched_barriers, sums kept in
+// registers and flushed once at the end (cdna_hip_programming.md section 7, in-kernel stamps)
+__device__ __forceinline__ unsigned long long stamp_() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#define PHASE_T0() unsigned long long pt_[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long t_prev_ = stamp_()
+#define PHASE(idx) do { const unsigned long long t_now_ = stamp_(); pt_[idx] += t_now_ - t_prev_; t_prev_ = t_now_; } while (0)
+#define PHASE_FLUSH() do { if (tid == 0) { _Pragma("unroll") for (int i_ = 0; i_ < 16; i_++) atomicAdd(&s.phase_cyc[i_], pt_[i_]); } } while (0)
 #else
 #define PHASE_T0() do {} while (0)
 #define PHASE(idx) do {} while (0)
+#define PHASE_FLUSH() do {} while (0)
 #endif
 template <int I, int N, typename F> __device__ __forceinline__ void static_for(F &&f) {
     if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
@@ -28,16 +39,18 @@ template <int I, int N, typename F> __device__ __forceinline__ void static_for(F
 // DPP controls (gfx90a+): row_shr:n = 0x110+n, row_ror:n = 0x120+n, row_newbcast:n = 0x150+n; a "row" is 16 lanes,
 // exactly one 16-lane env group, so these are single full-rate VALU modifiers instead of ds_bpermute round trips
 template <int CTRL, bool ZERO_OOB> __device__ __forceinline__ float dpp_f(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, ZERO_OOB));
+    // mov_dpp leaves "old" undefined, so no init move is emitted and the DPP combine pass can fold the move into
+    // its consumer (v_fmac_f32_dpp); every control used here reads a valid lane or (ZERO_OOB) wants 0
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), CTRL, 0xf, 0xf, ZERO_OOB));
 }
 template <int CTRL, bool ZERO_OOB> __device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, ZERO_OOB); }
 // value of lane LANE of the group, in every lane of the group
 template <int G, int LANE> __device__ __forceinline__ float gbcast(float v) {
-    if constexpr (G == 16) return dpp_f<0x150 + LANE, false>(v); else return __shfl(v, LANE, G);
+    if constexpr (G == 16) return dpp_f<0x150 + LANE, true>(v); else return __shfl(v, LANE, G);
 }
 template <int G> __device__ __forceinline__ float gsum(float v) {
     if constexpr (G == 16) {
-        v += dpp_f<0x128, false>(v); v += dpp_f<0x124, false>(v); v += dpp_f<0x122, false>(v); v += dpp_f<0x121, false>(v);
+        v += dpp_f<0x128, true>(v); v += dpp_f<0x124, true>(v); v += dpp_f<0x122, true>(v); v += dpp_f<0x121, true>(v);
         return v;
     } else {
 #pragma unroll
@@ -59,9 +72,10 @@ template <int G> __device__ __forceinline__ int glast(int v) {   // value of the
     if constexpr (G == 16) return dpp_i<0x15F, false>(v); else return __shfl(v, G - 1, G);
 }
 
-// in-register cooperative Cholesky: lane c holds row c (entries k <= c) of an SPD matrix; on return row c of L
-// and invd = 1 / L[c][c]
-template <int G> __device__ __forceinline__ bool chol_g(float (&row)[G], float &invd, int nv, int c) {
+// in-register cooperative Cholesky: lane c holds row c (entries k <= c) of an SPD matrix; on return row c of L in
+// row[0..c] (entries k > c are scratch) and invd = 1 / L[c][c].  Columns j >= ndense are known to have no
+// off-diagonal entries (block-diagonal tail of M): only their pivots are taken.
+template <int G> __device__ __forceinline__ bool chol_g(float (&row)[G], float &invd, int nv, int ndense, int c) {
     bool ok = true;
     invd = 1.f;
     static_for<0, G>([&](auto jc) {
@@ -69,15 +83,16 @@ template <int G> __device__ __forceinline__ bool chol_g(float (&row)[G], float &
         if (j < nv) {
             float ajj = gbcast<G, j>(row[j]);
             if (!(ajj >= HSR_MINVAL)) { ok = false; ajj = 1.f; }
-            const float d = sqrtf(ajj), inv = __builtin_amdgcn_rcpf(d);
-            const float lcj = (c == j) ? d : row[j] * inv;
+            const float inv = __builtin_amdgcn_rsqf(ajj);            // 1 ulp; the factor only shapes a Newton / Euler solve
+            const float lcj = row[j] * inv;                          // lane j: ajj * rsq(ajj) = sqrt(ajj)
             if (c == j) invd = inv;
             row[j] = lcj;
-            static_for<j + 1, G>([&](auto ic) {
-                constexpr int i = decltype(ic)::value;
-                const float li = gbcast<G, i>(lcj);
-                if (i <= c) row[i] -= lcj * li;
-            });
+            if (j < ndense) {
+                static_for<j + 1, G>([&](auto ic) {
+                    constexpr int i = decltype(ic)::value;
+                    row[i] -= lcj * gbcast<G, i>(lcj);               // unconditional: entries i > c are never read
+                });
+            }
         }
     });
     return ok;
@@ -85,29 +100,32 @@ template <int G> __device__ __forceinline__ bool chol_g(float (&row)[G], float &
 // solve L L^T x = b with lane c holding row c of L, invd and b_c; tile = G*(G+1) floats of LDS scratch.
 // Contains two workgroup barriers: must be called by every thread of the block.
 template <int G> __device__ __forceinline__ float chol_solve_g(const float (&row)[G], float invd, float b, int nv, int c, float *tile) {
+    float lo[G];
+#pragma unroll
+    for (int k = 0; k < G; k++) lo[k] = (k < c) ? row[k] : 0.f;     // strictly lower part, zero elsewhere
     float sacc = b, y = 0.f;
     static_for<0, G>([&](auto jc) {
         constexpr int j = decltype(jc)::value;
         if (j < nv) {
             const float yj = gbcast<G, j>(sacc * invd);
             if (c == j) y = yj;
-            if (c > j) sacc -= row[j] * yj;
+            sacc -= lo[j] * yj;
         }
     });
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < G; k++) tile[c * (G + 1) + k] = (k <= c) ? row[k] : 0.f;
+    for (int k = 0; k < G; k++) tile[c * (G + 1) + k] = lo[k];
     __syncthreads();
     float lt[G];
 #pragma unroll
-    for (int k = 0; k < G; k++) lt[k] = tile[k * (G + 1) + c];      // L[k][c]
+    for (int k = 0; k < G; k++) lt[k] = tile[k * (G + 1) + c];      // L[k][c] for k > c, 0 otherwise
     float s2 = y, x = 0.f;
     static_for<0, G>([&](auto jc) {
         constexpr int j = G - 1 - decltype(jc)::value;
         if (j < nv) {
             const float xj = gbcast<G, j>(s2 * invd);
             if (c == j) x = xj;
-            if (c < j) s2 -= lt[j] * xj;
+            s2 -= lt[j] * xj;
         }
     });
     return x;
@@ -242,6 +260,29 @@ __global__ void __launch_bounds__(64) k_solve_g(DevModel m, DevState s, int mode
 #pragma unroll
         for (int i = 0; i < 8; i++) { const int idx = c + i * G; if (idx < n4) dst[idx] = tmp[i]; }
     }
+    // values only needed at the very end (quaternion of a free joint, goal test, counters) are fetched now as well
+    q4 quat0; quat0.w = 1; quat0.x = quat0.y = quat0.z = 0;
+    if (valid && isdof && c == my_quat_lane && my_type == DOF_FREE_ANG) {
+        quat0.w = s.qpos[(size_t)my_qadr * N + e]; quat0.x = s.qpos[(size_t)(my_qadr + 1) * N + e];
+        quat0.y = s.qpos[(size_t)(my_qadr + 2) * N + e]; quat0.z = s.qpos[(size_t)(my_qadr + 3) * N + e];
+    }
+    bool reach = false;
+    float time0 = 0;
+    int nsteps0 = 0;
+    if (valid && c == 0) {
+        time0 = s.time[e]; nsteps0 = s.nsteps[e];
+        if (goal_body >= 0 && mode != 0) {
+            // a-3 goal test on the xpos of this substep's forward pass (computed by k_kinematics)
+            const v3 goal = mk3(s.mocap[e], s.mocap[N + e], s.mocap[2 * N + e]);
+            v3 bp = goal;
+            if (!m.body_mocap[goal_body]) {
+                const int l = m.body_link[goal_body];
+                View xpos{s.xpos + e, N}, xmat{s.xmat + e, N};
+                bp = xpos.get3(l) + mulmv(xmat.getm(l), ld3(m.body_pos, goal_body));
+            }
+            reach = norm(bp - goal) < geofence;
+        }
+    }
     vQvel[c] = qvel_c; vWarm[c] = warm_c;
 #pragma unroll
     for (int k = 0; k < G + 1; k++) M[c * MS + k] = 0.f;
@@ -256,6 +297,16 @@ __global__ void __launch_bounds__(64) k_solve_g(DevModel m, DevState s, int mode
     // ---------------- phase B/C: inertia rows (a-2.2) and bias force (a-2.5), lane = dof
     float bias_c = 0;
     if (isdof) {
+        // ancestors of dof c (c itself first), gathered once; per ancestor an accumulator in registers, so the
+        // link loop has no LDS read-modify-write chain
+        int anc[8];
+        int nd = 0;
+        {
+            int k = c;
+#pragma unroll
+            for (int d = 0; d < 8; d++) { anc[d] = k >= 0 ? k : 0; if (k >= 0) { nd = d + 1; k = sParent[k]; } }
+        }
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         for (int l = 1; l < m.nlink; l++) {
             if (!((sMask[l] >> c) & 1)) continue;
             const float *q = lk + 15 * l;
@@ -264,12 +315,18 @@ __global__ void __launch_bounds__(64) k_solve_g(DevModel m, DevState s, int mode
             const v3 v = jpc * sMass[l];
             const v3 u = mk3(q[3] * a_c.x + q[6] * a_c.y + q[7] * a_c.z, q[6] * a_c.x + q[4] * a_c.y + q[8] * a_c.z, q[7] * a_c.x + q[8] * a_c.y + q[5] * a_c.z);
             bias_c += dot(jpc, F) + dot(a_c, Nt);
-            for (int k = c; k >= 0; k = sParent[k]) {
-                const v3 ak = mk3(kAng[3 * k], kAng[3 * k + 1], kAng[3 * k + 2]);
-                const v3 jpk = mk3(kLin[3 * k], kLin[3 * k + 1], kLin[3 * k + 2]) + cross(ak, com - mk3(kAnc[3 * k], kAnc[3 * k + 1], kAnc[3 * k + 2]));
-                M[c * MS + k] += dot(jpk, v) + dot(ak, u);
+#pragma unroll
+            for (int d = 0; d < 8; d++) {
+                if (d < nd) {
+                    const int k = anc[d];
+                    const v3 ak = mk3(kAng[3 * k], kAng[3 * k + 1], kAng[3 * k + 2]);
+                    const v3 jpk = mk3(kLin[3 * k], kLin[3 * k + 1], kLin[3 * k + 2]) + cross(ak, com - mk3(kAnc[3 * k], kAnc[3 * k + 1], kAnc[3 * k + 2]));
+                    acc[d] += dot(jpk, v) + dot(ak, u);
+                }
             }
         }
+#pragma unroll
+        for (int d = 0; d < 8; d++) if (d < nd) M[c * MS + anc[d]] = acc[d];
     }
     float qfs_c = 0;
     if (isdof) {
@@ -300,7 +357,7 @@ __global__ void __launch_bounds__(64) k_solve_g(DevModel m, DevState s, int mode
 #pragma unroll
         for (int k = 0; k < G; k++) Lr[k] = Mrow[k];
         float invd;
-        if (!chol_g<G>(Lr, invd, nv, c)) bad = 1;
+        if (!chol_g<G>(Lr, invd, nv, m.ndense, c)) bad = 1;
         qas_c = chol_solve_g<G>(Lr, invd, qfs_c, nv, c, tile);
         if (!isdof) qas_c = 0;
     }
@@ -444,8 +501,12 @@ __global__ void __launch_bounds__(64) k_solve_g(DevModel m, DevState s, int mode
     const float tol = m.tolerance, scale = 1.0f / (m.meaninertia * (nv > 1 ? nv : 1));
     float cost = 0, Ma_c = 0;
     // total cost at the acceleration stored in `va`; leaves Ma, jar, gr, dw and the cone records in LDS
+    // zones_changed: some constraint switched between its quadratic pieces (limit on/off, cone top/bottom) or is in
+    // the curved middle zone, relative to the previous evaluation.  If an exact Newton step + exact line search
+    // lands on a point with unchanged pieces, that point minimises the current quadratic piece: converged.
+    bool zones_changed = true;
     auto eval_at = [&](const float *va) -> float {
-        float ma = 0;
+        float ma = 0, unstable = 0.f;
 #pragma unroll
         for (int k = 0; k < G; k++) ma += Mrow[k] * va[k];
         Ma_c = isdof ? ma : 0.f;
@@ -455,8 +516,9 @@ __global__ void __launch_bounds__(64) k_solve_g(DevModel m, DevState s, int mode
             for (int k = 0; k < nv; k++) sacc += J[r * RS + k] * va[k];
             rJar[r] = sacc;
             if (r < nlim) {
-                if (sacc < 0) { part += 0.5f * rD[r] * sacc * sacc; rGr[r] = rD[r] * sacc; rDw[r] = rD[r]; }
-                else { rGr[r] = 0; rDw[r] = 0; }
+                const bool was = rDw[r] != 0.f;
+                if (sacc < 0) { part += 0.5f * rD[r] * sacc * sacc; rGr[r] = rD[r] * sacc; rDw[r] = rD[r]; unstable += was ? 0.f : 1.f; }
+                else { rGr[r] = 0; rDw[r] = 0; unstable += was ? 1.f : 0.f; }
             }
         }
         __syncthreads();
@@ -471,11 +533,14 @@ __global__ void __launch_bounds__(64) k_solve_g(DevModel m, DevState s, int mode
             ConeOut o;
             cone_eval2(dim, cr[CR_MU], fri, D, x, o);
             part += o.cost;
+            // a cone that changed zone, or sits in the (non-quadratic) middle zone, keeps the Newton loop going
+            if ((int)cr[CR_ZONE] != o.zone || o.zone == 2) unstable += 1.f;
             cr[CR_ZONE] = (float)o.zone; cr[CR_DM] = o.Dm; cr[CR_K3] = o.k3;
 #pragma unroll
             for (int j = 0; j < 6; j++) { cr[CR_GN + j] = o.gn[j]; cr[CR_U + j] = o.u[j]; if (j < dim) { rGr[adr + j] = o.g[j]; rDw[adr + j] = o.dw[j]; } }
         }
         const float tot = gsum<G>(part);
+        zones_changed = gsum<G>(unstable) > 0.f;
         __syncthreads();
         return tot;
     };
@@ -503,7 +568,6 @@ __global__ void __launch_bounds__(64) k_solve_g(DevModel m, DevState s, int mode
         }
         const float gnorm = sqrtf(gsum<G>(grad_c * grad_c));
         if (scale * gnorm < tol) active = false;
-        PHASE(7);
         // Hessian rows H = M + J^T (d2s) J, lane = row c of H.  with_neg = false drops the negative rank-1 part
         // of the middle-zone cone Hessians (a PSD majorant), used only if the fp32 factorisation fails.
         float Hrow[G];
@@ -546,12 +610,12 @@ __global__ void __launch_bounds__(64) k_solve_g(DevModel m, DevState s, int mode
         build_H(true);
         PHASE(8);
         float hinvd;
-        bool hfail = !chol_g<G>(Hrow, hinvd, nv, c) && active;
+        bool hfail = !chol_g<G>(Hrow, hinvd, nv, nv, c) && active;
         if (__syncthreads_or(hfail)) {
             // rare: rebuild with the PSD majorant for every group of the block (cheap, keeps barriers uniform)
             const bool use_neg = !hfail;
             build_H(use_neg);
-            hfail = !chol_g<G>(Hrow, hinvd, nv, c) && active;
+            hfail = !chol_g<G>(Hrow, hinvd, nv, nv, c) && active;
             if (hfail) active = false;
         }
         float search_c = chol_solve_g<G>(Hrow, hinvd, -grad_c, nv, c, tile);
@@ -608,6 +672,7 @@ __global__ void __launch_bounds__(64) k_solve_g(DevModel m, DevState s, int mode
             const float gtol = tol * m.ls_tolerance * snorm / scale;
             float dp, hp, lo = 0, hi = -1;
             ls_eval(0.f, dp, hp);
+            const float dp0abs = fabsf(dp);
             // fp32 termination: the Newton decrement -dp/2 predicts the cost decrease without the
             // cancellation of (cost - newcost) between two large fp32 costs
             if (dp >= 0 || hp <= 0 || scale * 0.5f * (-dp) < tol) active = false;
@@ -615,7 +680,9 @@ __global__ void __launch_bounds__(64) k_solve_g(DevModel m, DevState s, int mode
                 alpha = -dp / hp;
                 for (int k = 0; k < m.ls_iterations; k++) {
                     ls_eval(alpha, dp, hp);
-                    if (fabsf(dp) < gtol) break;
+                    // fp32: the slope cannot be resolved below ~1e-6 of its initial value; MuJoCo's absolute
+                    // gtol (tolerance * ls_tolerance * |search| / scale) is kept as the primary criterion
+                    if (fabsf(dp) < fmaxf(gtol, 1e-5f * dp0abs)) break;
                     if (dp < 0) lo = alpha; else hi = alpha;
                     float nxt = alpha - dp / hp;
                     if (!(nxt > lo) || (hi > 0 && !(nxt < hi))) nxt = hi > 0 ? 0.5f * (lo + hi) : 2 * alpha;
@@ -629,7 +696,7 @@ __global__ void __launch_bounds__(64) k_solve_g(DevModel m, DevState s, int mode
         if (active) vQacc[c] += alpha * search_c;
         __syncthreads();
         const float newcost = eval_at(vQacc);
-        if (active) { iter++; cost = newcost; }
+        if (active) { iter++; cost = newcost; if (!zones_changed) active = false; }
         PHASE(11);
     }
     float qacc_c = vQacc[c], qfc_c = 0;
@@ -641,6 +708,7 @@ __global__ void __launch_bounds__(64) k_solve_g(DevModel m, DevState s, int mode
     }
     if (valid && c == 0) { s.ncon[e] = ncon; s.nefc[e] = nefc; s.niter[e] = iter; }
     if (mode == 0) {
+        PHASE_FLUSH();
         const float bsum = gsum<G>((float)bad);
         if (valid && c == 0 && bsum > 0) s.bad[e] = 1;
         return;
@@ -655,7 +723,7 @@ __global__ void __launch_bounds__(64) k_solve_g(DevModel m, DevState s, int mode
 #pragma unroll
         for (int k = 0; k < G; k++) Ar[k] = Mrow[k] + ((k == c) ? h * damp_c : 0.f);
         float ainvd;
-        if (!chol_g<G>(Ar, ainvd, nv, c)) bad = 1;
+        if (!chol_g<G>(Ar, ainvd, nv, m.ndense, c)) bad = 1;
         acc_c = chol_solve_g<G>(Ar, ainvd, qfs_c + qfc_c, nv, c, tile);
     }
     const float vnew = qvel_c + h * acc_c;
@@ -677,8 +745,7 @@ __global__ void __launch_bounds__(64) k_solve_g(DevModel m, DevState s, int mode
                 const v3 ax = w * (1.0f / wn);
                 float sn, cs;
                 sincosf(0.5f * angle, &sn, &cs);
-                q4 q, qr;
-                q.w = s.qpos[(size_t)adr * N + e]; q.x = s.qpos[(size_t)(adr + 1) * N + e]; q.y = s.qpos[(size_t)(adr + 2) * N + e]; q.z = s.qpos[(size_t)(adr + 3) * N + e];
+                q4 q = quat0, qr;
                 qr.w = cs; qr.x = ax.x * sn; qr.y = ax.y * sn; qr.z = ax.z * sn;
                 q = qnormalized(qmul(q, qr));
                 s.qpos[(size_t)adr * N + e] = q.w; s.qpos[(size_t)(adr + 1) * N + e] = q.x; s.qpos[(size_t)(adr + 2) * N + e] = q.y; s.qpos[(size_t)(adr + 3) * N + e] = q.z;
@@ -688,20 +755,11 @@ __global__ void __launch_bounds__(64) k_solve_g(DevModel m, DevState s, int mode
     PHASE(13);
     const float bsum = gsum<G>((float)bad);
     if (valid && c == 0) {
-        s.time[e] += h;
-        s.nsteps[e] += 1;
+        s.time[e] = time0 + h;
+        s.nsteps[e] = nsteps0 + 1;
         if (bsum > 0) s.bad[e] = 1;
-        // a-3 / a-4 goal test on the xpos of this substep's forward pass, latch done
-        if (goal_body >= 0) {
-            v3 bp;
-            const v3 goal = mk3(s.mocap[e], s.mocap[N + e], s.mocap[2 * N + e]);
-            if (m.body_mocap[goal_body]) bp = goal;
-            else {
-                const int l = m.body_link[goal_body];
-                View xpos{s.xpos + e, N}, xmat{s.xmat + e, N};
-                bp = xpos.get3(l) + mulmv(xmat.getm(l), ld3(m.body_pos, goal_body));
-            }
-            if (norm(bp - goal) < geofence) s.done[e] = 1;
-        }
+        if (reach) s.done[e] = 1;          // a-4: latch; this env skips the remaining substeps of the env-step
     }
+    PHASE(14);
+    PHASE_FLUSH();
 }

@@ -20,9 +20,9 @@ L.hsr_batch_phase_cycles(sim._b, buf)
 ctrl = rng.uniform(m.act_ctrlrange[:, 0], m.act_ctrlrange[:, 1], (n, m.nu)).astype(np.float32)
 sim.step(ctrl, 300, m.body_id('block0'), 0.05)
 L.hsr_batch_phase_cycles(sim._b, buf)
-v = np.array(list(buf), dtype=np.float64)[:14]
-names = ['A load', 'B/C M+bias', 'D chol M', 'E1-2 limits+compact', 'E3 contact rec', 'E4-5 J rows', 'F0 warm evals', 'F grad', 'F hess',
-         'F chol+solve', 'F linesearch', 'F update+eval', 'out', 'G euler']
+v = np.array(list(buf), dtype=np.float64)[:15]
+names = ['A load', 'B/C M+bias', 'D chol M+solve', 'E1-2 limits+compact', 'E3 contact rec', 'E4-5 J rows', 'F0 warm evals', 'F grad',
+         'F hess', 'F chol+solve', 'F ls setup+ls', 'F update+eval', 'out', 'G euler', 'tail']
 tot = v.sum()
 for nm, x in zip(names, v):
     print(f'{nm:22s} {x / tot * 100:6.2f} %   {x / (2048 * 300):9.0f} cyc/block/substep')
