@@ -325,7 +325,7 @@ _ARRAY_FIELDS = [
     "dof_invweight0", "dof_limited", "dof_range", "dof_solref", "dof_solimp",
     "body_link", "body_pos", "body_quat", "body_mocap",
     "geom_type", "geom_link", "geom_body", "geom_pos", "geom_quat", "geom_size", "geom_rbound",
-    "geom_condim", "geom_meshadr", "geom_meshnum", "geom_invweight",
+    "geom_condim", "geom_meshadr", "geom_meshnum", "geom_invweight", "geom_aabb",
     "mesh_vert",
     "pair_geom1", "pair_geom2", "pair_fn", "pair_condim", "pair_slot", "pair_friction",
     "pair_solref", "pair_solimp",
@@ -698,7 +698,19 @@ def compile_model(dofs: Sequence[str] = ("slide_x", "slide_y"), n_blocks: int = 
                 rbound = g.size[0]; size = g.size
             else:
                 rbound = 0.0; size = g.size
-            g_rec.append(dict(type=g.type, link=int(body_link[i]), body=i, pos=pos, quat=quat,
+            # box containing the geom in its own frame: centre(3) + half extents(3); tight (asymmetric) for hulls
+            if g.type == GEOM_MESH:
+                lo_, hi_ = verts.min(0), verts.max(0)
+                aabb = np.concatenate([(lo_ + hi_) / 2, (hi_ - lo_) / 2])
+            elif g.type == GEOM_CYLINDER:
+                aabb = np.array([0, 0, 0, g.size[0], g.size[0], g.size[1]])
+            elif g.type == GEOM_SPHERE:
+                aabb = np.array([0, 0, 0, g.size[0], g.size[0], g.size[0]])
+            elif g.type == GEOM_BOX:
+                aabb = np.concatenate([np.zeros(3), g.size])
+            else:
+                aabb = np.zeros(6)
+            g_rec.append(dict(type=g.type, link=int(body_link[i]), body=i, pos=pos, quat=quat, aabb=aabb,
                               size=size, rbound=rbound, condim=g.condim, meshadr=meshadr,
                               meshnum=meshnum, g=g))
             geom_names.append(g.name if g.mesh is None else f"{b.name}:{g.mesh}")
@@ -789,6 +801,7 @@ def compile_model(dofs: Sequence[str] = ("slide_x", "slide_y"), n_blocks: int = 
         geom_meshadr=np.array([g["meshadr"] for g in g_rec], dtype=np.int32),
         geom_meshnum=np.array([g["meshnum"] for g in g_rec], dtype=np.int32),
         geom_invweight=np.zeros((ngeom, 2)),
+        geom_aabb=np.array([g["aabb"] for g in g_rec]).reshape(ngeom, 6),
         mesh_vert=mesh_vert,
         pair_geom1=np.array([p["g1"] for p in pairs], dtype=np.int32),
         pair_geom2=np.array([p["g2"] for p in pairs], dtype=np.int32),

@@ -12,6 +12,7 @@ __global__ void __launch_bounds__(64) k_kinematics(DevModel m, DevState s) {
     // written out env-major with coalesced stores, so that the solver's 16-lane groups read whole 256-B lines
     // instead of 4-byte pieces of 64 different lines.
     extern __shared__ float ktile[];
+    if (blockIdx.x == 0) for (int i = threadIdx.x; i < m.npair_pad; i += 64) s.pair_count[i] = 0;   // work lists of k_cull
     const int e_raw = blockIdx.x * 64 + threadIdx.x;
     const bool live = e_raw < s.N && !s.done[e_raw < s.N ? e_raw : 0];
     const int e = live ? e_raw : 0;
@@ -163,6 +164,7 @@ __global__ void __launch_bounds__(64) k_kinematics(DevModel m, DevState s) {
 struct Geom {
     int type, nvert;
     v3 pos, size;
+    v3 bc, bh;                // bounding box in the geom frame: world centre, half extents (tight for hulls)
     m3 mat;
     const float4 *verts;      // hull vertices staged in LDS (xyz, w unused); all lanes of the wave share the mesh
 };
@@ -176,6 +178,8 @@ __device__ __forceinline__ Geom load_geom(const DevModel &m, const DevState &s, 
     G.mat = mulmm(R, ldm(m.geom_mat, g));
     G.type = m.geom_type[g];
     G.size = ld3(m.geom_size, g);
+    G.bc = G.pos + mulmv(G.mat, mk3(m.geom_aabb[6 * g], m.geom_aabb[6 * g + 1], m.geom_aabb[6 * g + 2]));
+    G.bh = mk3(m.geom_aabb[6 * g + 3], m.geom_aabb[6 * g + 4], m.geom_aabb[6 * g + 5]);
     G.verts = nullptr;
     G.nvert = m.geom_meshnum[g];
     return G;
@@ -194,24 +198,29 @@ __device__ __forceinline__ v3 support(const Geom &G, v3 dir) {
     } else if (G.type == GEOM_SPHERE) {
         loc = normalized(dl) * G.size.x;
     } else {
-        // mesh hull: exhaustive search, first maximum wins; vertices are LDS broadcast reads, 4 in flight
-        float bd = -3.0e38f;
-        loc = mk3(0, 0, 0);
+        // mesh hull: exhaustive search, first maximum wins (same tie-break as a sequential scan).  Two independent
+        // (value, index) chains over even/odd vertices give the VALU two dependency chains; the winning vertex is
+        // fetched once at the end.  Vertices are LDS broadcast reads.
+        float bA = -3.0e38f, bB = -3.0e38f;
+        int iA = 0, iB = 1;
         int i = 0;
         for (; i + 4 <= G.nvert; i += 4) {
             const float4 a = G.verts[i], b = G.verts[i + 1], c4 = G.verts[i + 2], d = G.verts[i + 3];
             const float ta = a.x * dl.x + a.y * dl.y + a.z * dl.z, tb = b.x * dl.x + b.y * dl.y + b.z * dl.z;
             const float tc = c4.x * dl.x + c4.y * dl.y + c4.z * dl.z, td = d.x * dl.x + d.y * dl.y + d.z * dl.z;
-            if (ta > bd) { bd = ta; loc = mk3(a.x, a.y, a.z); }
-            if (tb > bd) { bd = tb; loc = mk3(b.x, b.y, b.z); }
-            if (tc > bd) { bd = tc; loc = mk3(c4.x, c4.y, c4.z); }
-            if (td > bd) { bd = td; loc = mk3(d.x, d.y, d.z); }
+            iA = ta > bA ? i : iA; bA = fmaxf(bA, ta);
+            iB = tb > bB ? i + 1 : iB; bB = fmaxf(bB, tb);
+            iA = tc > bA ? i + 2 : iA; bA = fmaxf(bA, tc);
+            iB = td > bB ? i + 3 : iB; bB = fmaxf(bB, td);
         }
         for (; i < G.nvert; i++) {
             const float4 a = G.verts[i];
             const float t = a.x * dl.x + a.y * dl.y + a.z * dl.z;
-            if (t > bd) { bd = t; loc = mk3(a.x, a.y, a.z); }
+            if (i & 1) { iB = t > bB ? i : iB; bB = fmaxf(bB, t); } else { iA = t > bA ? i : iA; bA = fmaxf(bA, t); }
         }
+        const int best = (bB > bA || (bB == bA && iB < iA)) ? iB : iA;
+        const float4 w = G.verts[G.nvert > 0 ? best : 0];
+        loc = mk3(w.x, w.y, w.z);
     }
     return mulmv(G.mat, loc) + G.pos;
 }
@@ -379,6 +388,12 @@ __device__ void collide_box_box(const Geom &G1, const Geom &G2, ContactOut &out,
 
 // --- convex-convex: Minkowski Portal Refinement (libccd ccdMPRPenetration as used by mjc_Convex)
 struct Sup { v3 v, v1, v2; };
+#ifdef HSR_PHASE_TIMING
+__device__ int g_dbg_nsup_lane;   // unused placeholder to keep the symbol table stable
+#define DBG_COUNT_SUPPORT(ctr) (ctr)++
+#else
+#define DBG_COUNT_SUPPORT(ctr) do {} while (0)
+#endif
 __device__ __forceinline__ Sup mpr_support(const Geom &G1, const Geom &G2, v3 dir) {
     Sup s;
     s.v1 = support(G1, dir);
@@ -420,10 +435,20 @@ __device__ __forceinline__ float point_tri_dist2(v3 x0, v3 B, v3 Cc, v3 &wit, bo
 __device__ __forceinline__ v3 portal_dir(const Sup &p1, const Sup &p2, const Sup &p3) {
     return normalized(cross(p2.v - p1.v, p3.v - p1.v));
 }
+// branch-free selects keep the portal in registers (struct assignment under divergent ifs made the compiler
+// place the three portal points in a scratch array with dynamic indexing: every MPR step went through memory)
+__device__ __forceinline__ v3 sel3(bool c, v3 a, v3 b) { return mk3(c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z); }
+__device__ __forceinline__ Sup selS(bool c, const Sup &a, const Sup &b) {
+    Sup r;
+    r.v = sel3(c, a.v, b.v); r.v1 = sel3(c, a.v1, b.v1); r.v2 = sel3(c, a.v2, b.v2);
+    return r;
+}
 __device__ __forceinline__ void expand_portal(const Sup &p0, Sup &p1, Sup &p2, Sup &p3, const Sup &v4) {
     const v3 v4v0 = cross(v4.v, p0.v);
-    if (dot(p1.v, v4v0) > 0) { if (dot(p2.v, v4v0) > 0) p1 = v4; else p3 = v4; }
-    else { if (dot(p3.v, v4v0) > 0) p2 = v4; else p1 = v4; }
+    const bool d1 = dot(p1.v, v4v0) > 0, d2 = dot(p2.v, v4v0) > 0, d3 = dot(p3.v, v4v0) > 0;
+    // d1: (d2 ? p1 : p3) <- v4 ; !d1: (d3 ? p2 : p1) <- v4
+    const bool w1 = (d1 && d2) || (!d1 && !d3), w2 = !d1 && d3, w3 = d1 && !d2;
+    p1 = selS(w1, v4, p1); p2 = selS(w2, v4, p2); p3 = selS(w3, v4, p3);
 }
 __device__ __forceinline__ bool reach_tol(const Sup &p1, const Sup &p2, const Sup &p3, const Sup &v4, v3 dir, float tol) {
     const float dv4 = dot(v4.v, dir);
@@ -431,14 +456,18 @@ __device__ __forceinline__ bool reach_tol(const Sup &p1, const Sup &p2, const Su
     return mn < tol;
 }
 
-__device__ bool mpr_penetration(const Geom &G1, const Geom &G2, float tol, int maxit, float &depth, v3 &dirout, v3 &pos) {
+// returns true on penetration; otherwise `sep` is a proven separating direction of the Minkowski difference
+// (support(A-B, sep) . sep < 0) or zero when MPR gave up without one
+__device__ bool mpr_penetration(const Geom &G1, const Geom &G2, float tol, int maxit, float &depth, v3 &dirout, v3 &pos, v3 &sep, int &nsup) {
     const float eps = HSR_EPS;
     Sup p0, p1, p2, p3, v4;
     p0.v1 = G1.pos; p0.v2 = G2.pos; p0.v = p0.v1 - p0.v2;
     if (fabsf(p0.v.x) < eps && fabsf(p0.v.y) < eps && fabsf(p0.v.z) < eps) p0.v.x += 1e-5f;
     v3 dir = normalized(-p0.v);
-    p1 = mpr_support(G1, G2, dir);
-    if (dot(p1.v, dir) < eps) return false;
+    sep = mk3(0, 0, 0);
+    nsup = 0;
+    p1 = mpr_support(G1, G2, dir); nsup++;
+    if (dot(p1.v, dir) < eps) { sep = dir; return false; }
     dir = cross(p0.v, p1.v);
     if (dot(dir, dir) < eps * eps) {
         const float l1 = norm(p1.v);
@@ -447,30 +476,36 @@ __device__ bool mpr_penetration(const Geom &G1, const Geom &G2, float tol, int m
         return true;
     }
     dir = normalized(dir);
-    p2 = mpr_support(G1, G2, dir);
-    if (dot(p2.v, dir) < eps) return false;
+    p2 = mpr_support(G1, G2, dir); nsup++;
+    if (dot(p2.v, dir) < eps) { sep = dir; return false; }
     dir = normalized(cross(p1.v - p0.v, p2.v - p0.v));
-    if (dot(dir, p0.v) > 0) { const Sup t = p1; p1 = p2; p2 = t; dir = -dir; }
+    {
+        const bool sw = dot(dir, p0.v) > 0;
+        const Sup t1 = selS(sw, p2, p1), t2 = selS(sw, p1, p2);
+        p1 = t1; p2 = t2; dir = sel3(sw, -dir, dir);
+    }
     for (int it = 0;; it++) {
         if (it > 100) return false;
-        p3 = mpr_support(G1, G2, dir);
-        if (dot(p3.v, dir) < eps) return false;
-        bool cont = false;
-        if (dot(cross(p1.v, p3.v), p0.v) < -eps) { p2 = p3; cont = true; }
-        if (!cont && dot(cross(p3.v, p2.v), p0.v) < -eps) { p1 = p3; cont = true; }
-        if (!cont) break;
+        p3 = mpr_support(G1, G2, dir); nsup++;
+        if (dot(p3.v, dir) < eps) { sep = dir; return false; }
+        const bool c1 = dot(cross(p1.v, p3.v), p0.v) < -eps;
+        const bool c2 = !c1 && dot(cross(p3.v, p2.v), p0.v) < -eps;
+        p2 = selS(c1, p3, p2);
+        p1 = selS(c2, p3, p1);
+        if (!(c1 || c2)) break;
         dir = normalized(cross(p1.v - p0.v, p2.v - p0.v));
     }
     for (int it = 0;; it++) {
         dir = portal_dir(p1, p2, p3);
         if (dot(dir, p1.v) >= -eps) break;
-        v4 = mpr_support(G1, G2, dir);
-        if (dot(v4.v, dir) < -eps || reach_tol(p1, p2, p3, v4, dir, tol) || it > maxit) return false;
+        v4 = mpr_support(G1, G2, dir); nsup++;
+        if (dot(v4.v, dir) < -eps) { sep = dir; return false; }
+        if (reach_tol(p1, p2, p3, v4, dir, tol) || it > maxit) return false;
         expand_portal(p0, p1, p2, p3, v4);
     }
     for (int it = 0;; it++) {
         dir = portal_dir(p1, p2, p3);
-        v4 = mpr_support(G1, G2, dir);
+        v4 = mpr_support(G1, G2, dir); nsup++;
         if (reach_tol(p1, p2, p3, v4, dir, tol) || it > maxit) {
             v3 pdir;
             bool interior;
@@ -500,79 +535,164 @@ __device__ bool mpr_penetration(const Geom &G1, const Geom &G2, float tol, int m
     }
 }
 
-// half extents of a box that contains the geom in its own frame
-__device__ __forceinline__ v3 obb_half(const Geom &G) {
-    if (G.type == GEOM_CYLINDER) return mk3(G.size.x, G.size.x, G.size.y);
-    if (G.type == GEOM_SPHERE) return mk3(G.size.x, G.size.x, G.size.x);
-    return G.size;            // box half sizes; mesh: max |vertex coordinate| per axis (compiler.py)
-}
+// conservative culls on the oriented bounding boxes (centre G.bc, axes G.mat, half extents G.bh)
 __device__ __forceinline__ bool sphere_hits_obb(v3 c, float r, const Geom &B) {
-    const v3 l = mulmtv(B.mat, c - B.pos), h = obb_half(B);
-    const float dx = fmaxf(fabsf(l.x) - h.x, 0.f), dy = fmaxf(fabsf(l.y) - h.y, 0.f), dz = fmaxf(fabsf(l.z) - h.z, 0.f);
+    const v3 l = mulmtv(B.mat, c - B.bc);
+    const float dx = fmaxf(fabsf(l.x) - B.bh.x, 0.f), dy = fmaxf(fabsf(l.y) - B.bh.y, 0.f), dz = fmaxf(fabsf(l.z) - B.bh.z, 0.f);
     return dx * dx + dy * dy + dz * dz <= r * r;
 }
+// separating-axis test of two oriented boxes (15 axes); false = certainly disjoint
+__device__ __forceinline__ bool obb_overlap(const Geom &A, const Geom &B) {
+    const v3 d = B.bc - A.bc;
+    const float ha[3] = {A.bh.x, A.bh.y, A.bh.z}, hb[3] = {B.bh.x, B.bh.y, B.bh.z};
+    v3 Aa[3], Ba[3];
+    float C[3][3], aC[3][3], ta[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) { Aa[i] = col(A.mat, i); Ba[i] = col(B.mat, i); }
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        ta[i] = dot(d, Aa[i]);
+#pragma unroll
+        for (int j = 0; j < 3; j++) { C[i][j] = dot(Aa[i], Ba[j]); aC[i][j] = fabsf(C[i][j]) + 1e-6f; }
+    }
+    bool sep = false;
+#pragma unroll
+    for (int i = 0; i < 3; i++) sep |= fabsf(ta[i]) > ha[i] + hb[0] * aC[i][0] + hb[1] * aC[i][1] + hb[2] * aC[i][2];
+#pragma unroll
+    for (int j = 0; j < 3; j++) sep |= fabsf(ta[0] * C[0][j] + ta[1] * C[1][j] + ta[2] * C[2][j]) > hb[j] + ha[0] * aC[0][j] + ha[1] * aC[1][j] + ha[2] * aC[2][j];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+            const float ra = ha[i1] * aC[i2][j] + ha[i2] * aC[i1][j], rb = hb[j1] * aC[i][j2] + hb[j2] * aC[i][j1];
+            sep |= fabsf(ta[i2] * C[i1][j] - ta[i1] * C[i2][j]) > ra + rb;
+        }
+    return !sep;
+}
 
-// one wave per (64 envs, candidate pair): pair index blockIdx.y is wave-uniform, so the narrowphase
-// function, geom constants and mesh vertex tables are scalar data; lanes differ only in env state.
+// ---- two-stage collision: cull + compaction, then dense narrowphase ------------------------------------------------
+// Stage 1 (k_cull): one wave = 64 consecutive envs x one pair at a time.  Lanes whose pair survives the bounding tests are
+// compacted with a wave ballot and appended (one atomic per wave) to the pair's work list; every (env, pair) count is
+// reset to 0.  Stage 2 (k_narrow): one wave = 64 work items of ONE pair (so the narrowphase function, geom constants and
+// the LDS-staged hull vertices stay wave-uniform) with all lanes busy, instead of a few active lanes per wave.
+// List order depends on atomic arrival order, results do not: every item writes only its own (env, slot) records.
 #define MAXMESHV 256
-__global__ void __launch_bounds__(64) k_collide(DevModel m, DevState s) {
-    __shared__ float poly[2 * 8 * 3 * 64];
-    __shared__ float4 vbuf[2][MAXMESHV];
+
+__device__ __forceinline__ bool pair_cull(const DevModel &m, const Geom &G1, const Geom &G2, int g1, int g2) {
+    // mj_collideGeoms bounding-sphere test (margin 0), then tighter conservative culls on oriented bounding boxes
+    // (sphere vs box, box vs box SAT).  A contact needs the geoms to intersect, which implies every test passes, so
+    // the contact set is unchanged; the culls only spare the narrowphase.
+    if (G1.type == GEOM_PLANE) {
+        const v3 n = col(G1.mat, 2);
+        if (!(dot(G2.pos - G1.pos, n) <= m.geom_rbound[g2])) return false;
+        return dot(G2.bc - G1.pos, n) - (fabsf(dot(n, col(G2.mat, 0))) * G2.bh.x + fabsf(dot(n, col(G2.mat, 1))) * G2.bh.y + fabsf(dot(n, col(G2.mat, 2))) * G2.bh.z) <= 0.f;
+    }
+    const v3 r = G2.pos - G1.pos;
+    const float r1 = m.geom_rbound[g1], r2 = m.geom_rbound[g2], b = r1 + r2;
+    if (!(dot(r, r) <= b * b)) return false;
+    if (!(sphere_hits_obb(G2.pos, r2, G1) && sphere_hits_obb(G1.pos, r1, G2))) return false;
+    return obb_overlap(G1, G2);
+}
+
+__global__ void __launch_bounds__(64) k_cull(DevModel m, DevState s) {
     const int lane = threadIdx.x;
     const int e = blockIdx.x * 64 + lane;
     const bool live = e < s.N && !s.done[e < s.N ? e : 0];
     if (!__any(live)) return;
     const int es = live ? e : 0;
-    // one wave walks several candidate pairs; the pair index is wave-uniform, so the narrowphase function,
-    // geom constants and mesh tables are shared by all 64 envs of the wave
+    const int N = s.N;
     for (int pv = blockIdx.y; pv < m.npair; pv += gridDim.y) {
         const int p = __builtin_amdgcn_readfirstlane(pv);
         const int g1 = m.pair_geom1[p], g2 = m.pair_geom2[p];
-        Geom G1 = load_geom(m, s, g1, es), G2 = load_geom(m, s, g2, es);
+        const Geom G1 = load_geom(m, s, g1, es), G2 = load_geom(m, s, g2, es);
+        bool pass = live && pair_cull(m, G1, G2, g1, g2);
+#ifdef HSR_SKIP_NARROW
+        pass = false;
+#endif
+        const unsigned long long bal = __ballot(pass);
+        if (bal) {
+            const int first = __ffsll((long long)bal) - 1;
+            int base = 0;
+            if (lane == first) base = atomicAdd(&s.pair_count[p], __popcll(bal));
+            base = __shfl(base, first);
+            if (pass) s.pair_list[(size_t)p * N + base + __popcll(bal & ((1ull << lane) - 1ull))] = e;
+        }
+        if (live) s.ncon_pair[(size_t)e * m.npair_pad + p] = 0;
+    }
+}
+
+__global__ void __launch_bounds__(64) k_narrow(DevModel m, DevState s) {
+    __shared__ float poly[2 * 8 * 3 * 64];
+    __shared__ float4 vbuf[2][MAXMESHV];
+    __shared__ int sPre[256];
+    const int lane = threadIdx.x;
+    const int N = s.N;
+    // inclusive prefix of 64-item chunks per pair (npair <= 256), every wave computes the same table
+    int run = 0;
+    for (int base = 0; base < m.npair; base += 64) {
+        const int p = base + lane;
+        int ch = p < m.npair ? (s.pair_count[p] + 63) >> 6 : 0;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(ch, off); if (lane >= off) ch += t; }
+        if (p < m.npair) sPre[p] = run + ch;
+        run += __shfl(ch, 63);
+    }
+    __syncthreads();
+    const int total = run;
+    for (int cid = blockIdx.x; cid < total; cid += gridDim.x) {
+        // pair of this chunk: first p with sPre[p] > cid (binary search over the shared table; wave-uniform)
+        int lo = 0, hi = m.npair - 1;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (sPre[mid] > cid) hi = mid; else lo = mid + 1; }
+        const int p = __builtin_amdgcn_readfirstlane(lo);
+        const int k = (cid - (p > 0 ? sPre[p - 1] : 0)) * 64 + lane;
+        const int cnt = s.pair_count[p];
+        const bool act = k < cnt;
+        const int e = s.pair_list[(size_t)p * N + (act ? k : 0)];
+        const int g1 = m.pair_geom1[p], g2 = m.pair_geom2[p];
+        Geom G1 = load_geom(m, s, g1, e), G2 = load_geom(m, s, g2, e);
         ContactOut out;
-        out.con = s.con + (size_t)es * m.nslot * 8;
+        out.con = s.con + (size_t)e * m.nslot * 8;
         out.slot = m.pair_slot[p];
         out.maxcnt = m.pair_slot[p + 1] - m.pair_slot[p];
         out.cnt = 0;
-        // mj_collideGeoms bounding-sphere test (margin 0), then a tighter conservative cull: bounding sphere of one
-        // geom against the oriented bounding box of the other.  A contact needs the geoms to intersect, which
-        // implies every one of these tests passes, so the contact set is unchanged; the cull only spares the
-        // narrowphase (MPR over hull vertices) for pairs such as thin pan plate vs robot links.
-        bool pass;
-        if (G1.type == GEOM_PLANE) {
-            const v3 n = col(G1.mat, 2);
-            const float dc = dot(G2.pos - G1.pos, n);
-            pass = dc <= m.geom_rbound[g2];
-            if (pass) {
-                const v3 h = obb_half(G2);
-                pass = dc - (fabsf(dot(n, col(G2.mat, 0))) * h.x + fabsf(dot(n, col(G2.mat, 1))) * h.y + fabsf(dot(n, col(G2.mat, 2))) * h.z) <= 0.f;
-            }
-        } else {
-            const v3 r = G2.pos - G1.pos;
-            const float r1 = m.geom_rbound[g1], r2 = m.geom_rbound[g2], b = r1 + r2;
-            pass = dot(r, r) <= b * b;
-            if (pass) pass = sphere_hits_obb(G2.pos, r2, G1) && sphere_hits_obb(G1.pos, r1, G2);
+        const int fn = m.pair_fn[p];
+        __syncthreads();
+        if (fn == FN_PLANE_CONVEX || fn == FN_CONVEX) {
+            if (G1.type == GEOM_MESH) { const float4 *src = m.mesh_vert4 + m.geom_meshadr[g1]; for (int i = lane; i < G1.nvert; i += 64) vbuf[0][i] = src[i]; G1.verts = vbuf[0]; }
+            if (G2.type == GEOM_MESH) { const float4 *src = m.mesh_vert4 + m.geom_meshadr[g2]; for (int i = lane; i < G2.nvert; i += 64) vbuf[1][i] = src[i]; G2.verts = vbuf[1]; }
         }
-        pass = pass && live;
-        if (__any(pass)) {
-            const int fn = m.pair_fn[p];
-            if (fn == FN_PLANE_CONVEX || fn == FN_CONVEX) {
-                // stage the hull vertices of the mesh geoms in LDS (cooperative copy, one wave)
-                __syncthreads();
-                if (G1.type == GEOM_MESH) { const float4 *src = m.mesh_vert4 + m.geom_meshadr[g1]; for (int i = lane; i < G1.nvert; i += 64) vbuf[0][i] = src[i]; G1.verts = vbuf[0]; }
-                if (G2.type == GEOM_MESH) { const float4 *src = m.mesh_vert4 + m.geom_meshadr[g2]; for (int i = lane; i < G2.nvert; i += 64) vbuf[1][i] = src[i]; G2.verts = vbuf[1]; }
-                __syncthreads();
-            }
-            if (pass) {
-                if (fn == FN_PLANE_BOX) collide_plane_box(G1, G2, out);
-                else if (fn == FN_PLANE_CONVEX) collide_plane_convex(G1, G2, out);
-                else if (fn == FN_BOX_BOX) collide_box_box(G1, G2, out, poly, lane);
-                else {
-                    float depth; v3 dir, pos;
-                    if (mpr_penetration(G1, G2, m.mpr_tolerance, m.mpr_iterations, depth, dir, pos)) out.add(pos, dir, -depth);
+        __syncthreads();
+        if (act) {
+            if (fn == FN_PLANE_BOX) collide_plane_box(G1, G2, out);
+            else if (fn == FN_PLANE_CONVEX) collide_plane_convex(G1, G2, out);
+#ifndef HSR_SKIP_BOXBOX
+            else if (fn == FN_BOX_BOX) collide_box_box(G1, G2, out, poly, lane);
+#endif
+#ifndef HSR_SKIP_MPR
+            else {
+                // temporal coherence: the separating direction MPR proved last time is tried first; if it still
+                // separates (two support calls), MPR would again report "no intersection" - identical result
+                float *sx = s.sepax + (size_t)(3 * p) * N + e;
+                const v3 d = mk3(sx[0], sx[N], sx[2 * (size_t)N]);
+                bool still = false;
+                if (d.x != 0.f || d.y != 0.f || d.z != 0.f) still = dot(support(G1, d) - support(G2, -d), d) < -1e-7f;
+                if (!still) {
+                    float depth; v3 dir, pos, sep;
+                    int nsup = 0;
+                    if (mpr_penetration(G1, G2, m.mpr_tolerance, m.mpr_iterations, depth, dir, pos, sep, nsup)) { out.add(pos, dir, -depth); sep = mk3(0, 0, 0); }
+                    sx[0] = sep.x; sx[N] = sep.y; sx[2 * (size_t)N] = sep.z;
+#ifdef HSR_PHASE_TIMING
+                    atomicAdd(&s.phase_cyc[20], (unsigned long long)nsup); atomicMax(&s.phase_cyc[21], (unsigned long long)nsup); atomicAdd(&s.phase_cyc[22], 1ull);
+                    if (nsup > 20) atomicAdd(&s.phase_cyc[24], 1ull);
+#endif
                 }
+#ifdef HSR_PHASE_TIMING
+                else atomicAdd(&s.phase_cyc[23], 1ull);
+#endif
             }
+#endif
+            s.ncon_pair[(size_t)e * m.npair_pad + p] = out.cnt;
         }
-        if (live) s.ncon_pair[(size_t)e * m.npair_pad + p] = out.cnt;
     }
 }

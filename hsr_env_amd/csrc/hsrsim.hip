@@ -162,6 +162,7 @@ struct hsr_batch {
     int32_t *d_stage_i32 = nullptr;
     int hot_threads = 64;
     size_t hot_lds_bytes = 0;
+    int narrow_blocks = 2048;      // persistent-style grid of k_narrow (HSR_NARROW_BLOCKS overrides)
     int pairs_per_wave = 4;        // k_collide: pairs walked by one wave (HSR_PPW overrides)
     int solver = 1;                // 0: one lane per env (solve.h), 1: lane group per env (solve_g.h)
     int group = 16;
@@ -327,6 +328,7 @@ extern "C" int hsr_batch_create(const hsr_model *m, int n_envs, int device_id, h
     const int *sz = m->sizes;
     d.nq = sz[HSR_NQ]; d.nv = sz[HSR_NV]; d.nu = sz[HSR_NU]; d.nlink = sz[HSR_NLINK]; d.nbody = sz[HSR_NBODY];
     d.ngeom = sz[HSR_NGEOM]; d.npair = sz[HSR_NPAIR]; d.nslot = sz[HSR_NSLOT]; d.nconmax = sz[HSR_NCONMAX]; d.njmax = sz[HSR_NJMAX];
+    if (d.npair > 256) return fail(HSR_EINVAL, "more than 256 candidate geom pairs");
     d.nM = d.nv * (d.nv + 1) / 2;
     d.ndense = sz[13];
     d.timestep = (float)m->opt[0]; d.impratio = (float)m->opt[1]; d.gravz = (float)m->opt[2]; d.tolerance = (float)m->opt[3];
@@ -341,7 +343,7 @@ extern "C" int hsr_batch_create(const hsr_model *m, int n_envs, int device_id, h
     UF(dof_axis) UF(dof_pos) UF(dof_damping) UF(dof_invweight0) UF(dof_range) UF(dof_solref) UF(dof_solimp)
     UI(body_link) UI(body_mocap) UF(body_pos)
     UI(geom_type) UI(geom_link) UI(geom_meshadr) UI(geom_meshnum)
-    UF(geom_pos) UF(geom_size) UF(geom_rbound) UF(geom_invweight) UF(mesh_vert)
+    UF(geom_pos) UF(geom_size) UF(geom_rbound) UF(geom_invweight) UF(mesh_vert) UF(geom_aabb)
     UI(pair_geom1) UI(pair_geom2) UI(pair_fn) UI(pair_condim) UI(pair_slot)
     UF(pair_friction) UF(pair_solref) UF(pair_solimp)
     UI(act_dof) UF(act_gear) UF(act_kp) UF(act_ctrlrange) UF(act_forcerange)
@@ -395,7 +397,8 @@ extern "C" int hsr_batch_create(const hsr_model *m, int n_envs, int device_id, h
     DA(xpos, 3 * d.nlink) DA(xmat, 9 * d.nlink) DA(dof_ang, 3 * d.nv) DA(dof_lin, 3 * d.nv) DA(dof_anchor, 3 * d.nv) DA(link_dyn, 15 * d.nlink)
     s.kstride = (9 * d.nv + 15 * d.nlink + 15) & ~15;
     DA(kin_aos, s.kstride)
-    DA(con, 8 * d.nslot) DA(ncon_pair, d.npair_pad)
+    DA(con, 8 * d.nslot) DA(ncon_pair, d.npair_pad) DA(sepax, 3 * std::max(d.npair, 1)) DA(pair_list, std::max(d.npair, 1))
+    if ((rc = dalloc(b, &s.pair_count, (size_t)d.npair_pad))) return rc;
     DA(M, d.nM) DA(qacc, d.nv) DA(qacc_smooth, d.nv) DA(qfrc_smooth, d.nv) DA(qfrc_constraint, d.nv)
     DA(ncon, 1) DA(nefc, 1) DA(niter, 1)
     // solver workspace rows
@@ -420,6 +423,8 @@ extern "C" int hsr_batch_create(const hsr_model *m, int n_envs, int device_id, h
     // cooperative solver geometry: 16 lanes per env when nv <= 16, else 32
     b->group = d.nv <= 16 ? 16 : 32;
     {
+        const char *nbk = getenv("HSR_NARROW_BLOCKS");
+        if (nbk && atoi(nbk) > 0) b->narrow_blocks = atoi(nbk);
         const char *ppw = getenv("HSR_PPW");
         if (ppw && atoi(ppw) > 0) b->pairs_per_wave = atoi(ppw);
         const char *sv = getenv("HSR_SOLVER");
@@ -491,7 +496,10 @@ static void launch_substep(hsr_batch *b, int mode, int goal_body, float geofence
     rec();
     hipLaunchKernelGGL(k_kinematics, dim3((N + 63) / 64), dim3(64), (size_t)64 * (b->ds.kstride + 24 * b->dm.nlink + 1) * sizeof(float), st, b->dm, b->ds);
     rec();
-    if (b->dm.npair > 0) hipLaunchKernelGGL(k_collide, dim3((N + 63) / 64, (b->dm.npair + b->pairs_per_wave - 1) / b->pairs_per_wave), dim3(64), 0, st, b->dm, b->ds);
+    if (b->dm.npair > 0) {
+        hipLaunchKernelGGL(k_cull, dim3((N + 63) / 64, (b->dm.npair + b->pairs_per_wave - 1) / b->pairs_per_wave), dim3(64), 0, st, b->dm, b->ds);
+        hipLaunchKernelGGL(k_narrow, dim3(b->narrow_blocks), dim3(64), 0, st, b->dm, b->ds);
+    }
     rec();
     if (b->solver == 0) hipLaunchKernelGGL(k_solve, dim3((N + 63) / 64), dim3(64), b->hot_lds_bytes, st, b->dm, b->ds, mode, goal_body, geofence, debug);
     else if (b->solver == 2 && b->group == 16) hipLaunchKernelGGL(k_solve_mf<16>, dim3((N + 3) / 4), dim3(64), b->mf_lds_bytes, st, b->dm, b->ds, mode, goal_body, geofence, debug);

@@ -21,6 +21,7 @@ struct DevModel {
     const float *body_pos;
     const int *geom_type, *geom_link, *geom_meshadr, *geom_meshnum;
     const float *geom_pos, *geom_mat, *geom_size, *geom_rbound, *geom_invweight, *mesh_vert;
+    const float *geom_aabb;            // [ngeom][6] bounding box in the geom frame: centre, half extents
     const float4 *mesh_vert4;          // hull vertices padded to float4 (LDS staging in k_collide)
     const int *pair_geom1, *pair_geom2, *pair_fn, *pair_condim, *pair_slot;
     const float *pair_friction, *pair_solref, *pair_solimp;
@@ -47,6 +48,8 @@ struct DevState {
     //   con[(e * nslot + slot) * 8 + k]  (pos 0-2, normal 3-5, dist 6), ncon_pair[e * npair_pad + p]
     float *con;
     int *ncon_pair;
+    int *pair_count, *pair_list;   // per-pair work lists of the narrowphase: count[npair_pad], list[npair][N] env ids
+    float *sepax;             // [3 npair][N] cached separating direction per (pair, env) for the MPR pairs (0 = none)
     // dynamics / solver outputs kept for introspection
     float *M, *qacc, *qacc_smooth, *qfrc_smooth, *qfrc_constraint;
     int *ncon, *nefc, *niter;

@@ -559,6 +559,7 @@ __global__ void __launch_bounds__(64, 2) k_solve_mf(DevModel m, DevState s, int 
     float qfc_c = 0;
     if (nefc == 0) qacc_c = qas_c;
     else qfc_c = -jt_force();
+    PHASE(14);
     if (valid && isdof) {
         s.qacc[(size_t)c * N + e] = qacc_c;
         if (debug) { s.qacc_smooth[(size_t)c * N + e] = qas_c; s.qfrc_smooth[(size_t)c * N + e] = qfs_c; s.qfrc_constraint[(size_t)c * N + e] = qfc_c; }
@@ -581,16 +582,22 @@ __global__ void __launch_bounds__(64, 2) k_solve_mf(DevModel m, DevState s, int 
         for (int k = 0; k < G; k++) Ar[k] = Mrow[k] + ((k == c) ? h * damp_c : 0.f);
         float ainvd;
         if (!chol_g<G>(Ar, ainvd, nv, m.ndense, c)) bad = 1;
+        PHASE(15);
         acc_c = chol_solve_mf<G>(Ar, ainvd, qfs_c + qfc_c, nv, c);
     }
+    PHASE(12);
     const float vnew = isdof ? qvel_c + h * acc_c : 0.f;
     if (!(fabsf(vnew) <= 1e10f)) bad = 1;
     const float v1 = __shfl_down(vnew, 1, G), v2 = __shfl_down(vnew, 2, G);
+    PHASE(16);
     if (valid && isdof) {
         s.qvel[(size_t)c * N + e] = vnew;
         s.warm[(size_t)c * N + e] = qacc_c;
         if (my_type == DOF_SLIDE || my_type == DOF_HINGE || my_type == DOF_FREE_LIN) s.qpos[(size_t)my_qadr * N + e] = my_q + h * vnew;
-        else if (c == my_quat_lane) {
+    }
+    PHASE(17);
+    if (valid && isdof) {
+        if (my_type == DOF_FREE_ANG && c == my_quat_lane) {
             const v3 w = mk3(vnew, v1, v2);
             const float wn = norm(w), angle = wn * h;
             if (angle > 0) {
@@ -613,6 +620,6 @@ __global__ void __launch_bounds__(64, 2) k_solve_mf(DevModel m, DevState s, int 
         if (bsum > 0) s.bad[e] = 1;
         if (reach) s.done[e] = 1;
     }
-    PHASE(14);
+    PHASE(13);
     PHASE_FLUSH();
 }

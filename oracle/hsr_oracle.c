@@ -633,7 +633,13 @@ static void collide_box_box(const ho_model *m, ho_data *d, int pair, int g1, int
 /* --- convex-convex: Minkowski Portal Refinement (restates libccd's ccdMPRPenetration, used by
  *     MuJoCo's mjc_Convex); one contact per pair */
 typedef struct { double v[3], v1[3], v2[3]; } mpr_sup;
+/* diagnostics: support-pair evaluations of the last / all MPR calls (not thread safe; tests only) */
+static long ho_dbg_mpr_supports_ = 0, ho_dbg_mpr_calls_ = 0, ho_dbg_mpr_max_ = 0, ho_dbg_mpr_cur_ = 0;
+long ho_dbg_mpr_supports(void) { return ho_dbg_mpr_supports_; }
+long ho_dbg_mpr_calls(void) { return ho_dbg_mpr_calls_; }
+long ho_dbg_mpr_max(void) { return ho_dbg_mpr_max_; }
 static void mpr_support(const ho_model *m, const ho_data *d, int g1, int g2, const double *dir, mpr_sup *s) {
+    ho_dbg_mpr_supports_++; ho_dbg_mpr_cur_++;
     double nd[3] = { -dir[0], -dir[1], -dir[2] };
     support(m, d, g1, dir, s->v1); support(m, d, g2, nd, s->v2); sub3(s->v, s->v1, s->v2);
 }
@@ -762,7 +768,9 @@ static int mpr_penetration(const ho_model *m, const ho_data *d, int g1, int g2, 
 }
 static void collide_convex(const ho_model *m, ho_data *d, int pair, int g1, int g2) {
     double depth, dir[3], pos[3];
+    ho_dbg_mpr_calls_++; ho_dbg_mpr_cur_ = 0;
     if (mpr_penetration(m, d, g1, g2, &depth, dir, pos)) add_contact(m, d, pair, pos, dir, -depth);
+    if (ho_dbg_mpr_cur_ > ho_dbg_mpr_max_) ho_dbg_mpr_max_ = ho_dbg_mpr_cur_;
 }
 
 static void ho_collision(const ho_model *m, ho_data *d) {

@@ -20,10 +20,14 @@ L.hsr_batch_phase_cycles(sim._b, buf)
 ctrl = rng.uniform(m.act_ctrlrange[:, 0], m.act_ctrlrange[:, 1], (n, m.nu)).astype(np.float32)
 sim.step(ctrl, 300, m.body_id('block0'), 0.05)
 L.hsr_batch_phase_cycles(sim._b, buf)
-v = np.array(list(buf), dtype=np.float64)[:15]
+v = np.array(list(buf), dtype=np.float64)[:18]
 names = ['A load', 'B/C M+bias', 'D chol M+solve', 'E1-2 limits+compact', 'E3 contact rec', 'E4-5 J rows', 'F0 warm evals', 'F grad',
-         'F hess', 'F chol+solve', 'F ls setup+ls', 'F update+eval', 'out', 'G euler', 'tail']
+         'F hess', 'F chol+solve', 'F ls setup+ls', 'F update+eval', 'qfc..stores+G chol(12)', 'G solve..stores+tail(13)', 'loop exit+qfc jt_force(14)', 'G chol only(15)', 'vnew+shfl(16)', 'stores qvel/warm/qpos(17)']
 tot = v.sum()
 for nm, x in zip(names, v):
     print(f'{nm:22s} {x / tot * 100:6.2f} %   {x / (2048 * 300):9.0f} cyc/block/substep')
 print('total cyc/block/substep', tot / (2048 * 300))
+
+w = np.array(list(buf), dtype=np.float64)
+print('MPR: calls/substep %.1f  cache hits/substep %.1f  supports/call %.2f  max supports in a call %d  calls with >20 supports per substep %.2f' % (
+    w[22] / 300, w[23] / 300, w[20] / max(w[22], 1), w[21], w[24] / 300))
