@@ -6,22 +6,12 @@
 #include "devmath.h"
 #include "model.h"
 
-// ------------------------------------------------------------------ kinematics (a-2.1)
-__global__ void __launch_bounds__(64) k_kinematics(DevModel m, DevState s) {
-    // The solver's inputs (dof axes, per-link wrenches) are produced per lane in an LDS tile [64][kstride+1] and
-    // written out env-major with coalesced stores, so that the solver's 16-lane groups read whole 256-B lines
-    // instead of 4-byte pieces of 64 different lines.
-    extern __shared__ float ktile[];
-    if (blockIdx.x == 0) for (int i = threadIdx.x; i < m.npair_pad; i += 64) s.pair_count[i] = 0;   // work lists of k_cull
-    const int e_raw = blockIdx.x * 64 + threadIdx.x;
-    const bool live = e_raw < s.N && !s.done[e_raw < s.N ? e_raw : 0];
-    const int e = live ? e_raw : 0;
-    // per-lane LDS record: [kstride: solver inputs | 3 nlink xpos | 9 nlink xmat | 12 nlink link velocity state] (+1 pad)
-    const int N = s.N, TS = s.kstride + 24 * m.nlink + 1;
-    float *tl = ktile + threadIdx.x * TS;
-    if (live) {
-    View qpos{s.qpos + e, N}, xpos{tl + s.kstride, 1}, xmat{tl + s.kstride + 3 * m.nlink, 1};
-    View ang{tl, 1}, lin{tl + 3 * m.nv, 1}, anc{tl + 6 * m.nv, 1};
+// Kinematics + RNE velocity recursion of ONE env, serial over its links (mj_kinematics, mj_comPos, mj_comVel/mj_rne
+// velocity part).  All arrays are Views so that the same code serves the one-lane-per-env kernel (LDS tile per lane)
+// and the persistent per-env-group kernel (LDS record of the group).  Outputs: link poses, world dof axes/anchors,
+// per-link com(3) Iworld(6) F(3) N(3) in ld; lw/lvo/lal/lao are scratch (12 floats per link).
+__device__ void kin_env(const DevModel &m, View qpos, View qvel, View xpos, View xmat, View ang, View lin, View anc, View ld,
+                        View lw, View lvo, View lal, View lao) {
     m3 I;
 #pragma unroll
     for (int k = 0; k < 9; k++) I.a[k] = (k % 4 == 0) ? 1.f : 0.f;
@@ -82,8 +72,6 @@ __global__ void __launch_bounds__(64) k_kinematics(DevModel m, DevState s) {
     }
     // ---- link velocities / bias accelerations (qacc = 0) and the per-link wrench of mj_rne:
     //      F = m (a_com - g), N = I alpha + w x I w  (consumed by the solve kernel as bias = J^T [F; N])
-    View qvel{s.qvel + e, N}, ld{tl + 9 * m.nv, 1};
-    View lw{tl + s.kstride + 12 * m.nlink, 1}, lvo{tl + s.kstride + 15 * m.nlink, 1}, lal{tl + s.kstride + 18 * m.nlink, 1}, lao{tl + s.kstride + 21 * m.nlink, 1};
     lw.set3(0, mk3(0, 0, 0)); lvo.set3(0, mk3(0, 0, 0)); lal.set3(0, mk3(0, 0, 0)); lao.set3(0, mk3(0, 0, 0));
     for (int k = 0; k < 15; k++) ld[k] = 0;
     for (int l = 1; l < m.nlink; l++) {
@@ -138,6 +126,27 @@ __global__ void __launch_bounds__(64) k_kinematics(DevModel m, DevState s) {
         ld[b + 3] = I.a[0]; ld[b + 4] = I.a[4]; ld[b + 5] = I.a[8]; ld[b + 6] = I.a[1]; ld[b + 7] = I.a[2]; ld[b + 8] = I.a[5];
         ld[b + 9] = F.x; ld[b + 10] = F.y; ld[b + 11] = F.z; ld[b + 12] = Nt.x; ld[b + 13] = Nt.y; ld[b + 14] = Nt.z;
     }
+}
+
+// ------------------------------------------------------------------ kinematics (a-2.1)
+__global__ void __launch_bounds__(64) k_kinematics(DevModel m, DevState s) {
+    // The solver's inputs (dof axes, per-link wrenches) are produced per lane in an LDS tile [64][kstride+1] and
+    // written out env-major with coalesced stores, so that the solver's 16-lane groups read whole 256-B lines
+    // instead of 4-byte pieces of 64 different lines.
+    extern __shared__ float ktile[];
+    if (blockIdx.x == 0) for (int i = threadIdx.x; i < m.npair_pad; i += 64) s.pair_count[i] = 0;   // work lists of k_cull
+    const int e_raw = blockIdx.x * 64 + threadIdx.x;
+    const bool live = e_raw < s.N && !s.done[e_raw < s.N ? e_raw : 0];
+    const int e = live ? e_raw : 0;
+    // per-lane LDS record: [kstride: solver inputs | 3 nlink xpos | 9 nlink xmat | 12 nlink link velocity state] (+1 pad)
+    const int N = s.N, TS = s.kstride + 24 * m.nlink + 1;
+    float *tl = ktile + threadIdx.x * TS;
+    if (live) {
+    View qpos{s.qpos + e, N}, xpos{tl + s.kstride, 1}, xmat{tl + s.kstride + 3 * m.nlink, 1};
+    View ang{tl, 1}, lin{tl + 3 * m.nv, 1}, anc{tl + 6 * m.nv, 1};
+    View qvel{s.qvel + e, N}, ld{tl + 9 * m.nv, 1};
+    View lw{tl + s.kstride + 12 * m.nlink, 1}, lvo{tl + s.kstride + 15 * m.nlink, 1}, lal{tl + s.kstride + 18 * m.nlink, 1}, lao{tl + s.kstride + 21 * m.nlink, 1};
+    kin_env(m, qpos, qvel, xpos, xmat, ang, lin, anc, ld, lw, lvo, lal, lao);
     for (int i = 9 * m.nv + 15 * m.nlink; i < s.kstride; i++) tl[i] = 0.f;
     }
     __syncthreads();
@@ -169,10 +178,13 @@ struct Geom {
     const float4 *verts;      // hull vertices staged in LDS (xyz, w unused); all lanes of the wave share the mesh
 };
 
+__device__ __forceinline__ Geom load_geom_v(const DevModel &m, View xpos, View xmat, int g);
 __device__ __forceinline__ Geom load_geom(const DevModel &m, const DevState &s, int g, int e) {
+    return load_geom_v(m, View{s.xpos + e, s.N}, View{s.xmat + e, s.N}, g);
+}
+__device__ __forceinline__ Geom load_geom_v(const DevModel &m, View xpos, View xmat, int g) {
     Geom G;
     const int l = m.geom_link[g];
-    View xpos{s.xpos + e, s.N}, xmat{s.xmat + e, s.N};
     const m3 R = xmat.getm(l);
     G.pos = xpos.get3(l) + mulmv(R, ld3(m.geom_pos, g));
     G.mat = mulmm(R, ldm(m.geom_mat, g));
@@ -258,8 +270,8 @@ __device__ __forceinline__ void collide_plane_convex(const Geom &P, const Geom &
 }
 
 // --- box-box: SAT + reference-face clipping; polygon scratch lives in LDS ([buf][vertex][xyz][lane])
-#define POLY(buf, i, k) poly[(((buf) * 8 + (i)) * 3 + (k)) * 64 + lane]
-__device__ __forceinline__ int clip_poly(float *poly, int lane, int src, int n, v3 axis, float lim, v3 origin) {
+#define POLY(buf, i, k) poly[(((buf) * 8 + (i)) * 3 + (k)) * pstride + poff]
+__device__ __forceinline__ int clip_poly(float *poly, int pstride, int poff, int src, int n, v3 axis, float lim, v3 origin) {
     const int dst = src ^ 1;
     int no = 0;
     for (int i = 0; i < n; i++) {
@@ -277,7 +289,9 @@ __device__ __forceinline__ int clip_poly(float *poly, int lane, int src, int n, 
     return no;
 }
 
-__device__ void collide_box_box(const Geom &G1, const Geom &G2, ContactOut &out, float *poly, int lane) {
+// polygon scratch addressing: element (buf, vertex, xyz) lives at poly[((buf*8+vertex)*3+xyz)*pstride + poff]
+// (k_narrow: lane-interleaved pstride 64, poff lane; persistent kernel: private 48-float slot, pstride 1, poff 0)
+__device__ void collide_box_box_p(const Geom &G1, const Geom &G2, ContactOut &out, float *poly, int pstride, int poff) {
     v3 A[3], B[3];
     float s1[3] = {G1.size.x, G1.size.y, G1.size.z}, s2[3] = {G2.size.x, G2.size.y, G2.size.z};
 #pragma unroll
@@ -358,10 +372,10 @@ __device__ void collide_box_box(const Geom &G1, const Geom &G2, ContactOut &out,
         const float sv = ax == 0 ? sr[2] : (ax == 1 ? sr[0] : sr[1]);
         const float sa = ax == 0 ? sr[0] : (ax == 1 ? sr[1] : sr[2]);
         int np = 4, buf = 0;
-        np = clip_poly(poly, lane, buf, np, Au, su, pr); buf ^= 1;
-        if (np) { np = clip_poly(poly, lane, buf, np, -Au, su, pr); buf ^= 1; }
-        if (np) { np = clip_poly(poly, lane, buf, np, Av, sv, pr); buf ^= 1; }
-        if (np) { np = clip_poly(poly, lane, buf, np, -Av, sv, pr); buf ^= 1; }
+        np = clip_poly(poly, pstride, poff, buf, np, Au, su, pr); buf ^= 1;
+        if (np) { np = clip_poly(poly, pstride, poff, buf, np, -Au, su, pr); buf ^= 1; }
+        if (np) { np = clip_poly(poly, pstride, poff, buf, np, Av, sv, pr); buf ^= 1; }
+        if (np) { np = clip_poly(poly, pstride, poff, buf, np, -Av, sv, pr); buf ^= 1; }
         for (int k = 0; k < np; k++) {
             const v3 v = mk3(POLY(buf, k, 0), POLY(buf, k, 1), POLY(buf, k, 2));
             const float dist = dot(v - pr, nref) - sa;
@@ -385,6 +399,8 @@ __device__ void collide_box_box(const Geom &G1, const Geom &G2, ContactOut &out,
     }
 }
 #undef POLY
+__device__ __forceinline__ void collide_box_box(const Geom &G1, const Geom &G2, ContactOut &out, float *poly, int lane) { collide_box_box_p(G1, G2, out, poly, 64, lane); }
+__device__ __forceinline__ void collide_box_box_slot(const Geom &G1, const Geom &G2, ContactOut &out, float *slot) { collide_box_box_p(G1, G2, out, slot, 1, 0); }
 
 // --- convex-convex: Minkowski Portal Refinement (libccd ccdMPRPenetration as used by mjc_Convex)
 struct Sup { v3 v, v1, v2; };

@@ -19,6 +19,7 @@
 #include "solve.h"
 #include "solve_g.h"
 #include "solve_mf.h"
+#include "persist.h"
 
 static thread_local char g_err[512] = "";
 static int fail(int code, const char *fmt, const char *detail = "") {
@@ -166,7 +167,8 @@ struct hsr_batch {
     int pairs_per_wave = 4;        // k_collide: pairs walked by one wave (HSR_PPW overrides)
     int solver = 1;                // 0: one lane per env (solve.h), 1: lane group per env (solve_g.h)
     int group = 16;
-    size_t group_lds_bytes = 0, mf_lds_bytes = 0;
+    size_t group_lds_bytes = 0, mf_lds_bytes = 0, persist_lds_bytes = 0;
+    bool persist = false;          // whole env-step in one persistent kernel (k_env_step_mf); HSR_PERSIST=0 disables
     bool use_graph = true, profiling = false;
     std::map<GraphKey, hipGraphExec_t> graphs;
     float last_total_ms = 0, last_kernel_ms[3] = {0, 0, 0};
@@ -448,6 +450,33 @@ extern "C" int hsr_batch_create(const hsr_model *m, int n_envs, int device_id, h
             else HIPCHK(hipFuncSetAttribute((const void *)k_solve_mf<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->mf_lds_bytes));
         }
     }
+    if (b->solver == 2) {
+        const char *pe = getenv("HSR_PERSIST");
+        b->persist = !(pe && strcmp(pe, "0") == 0);
+        const int total = b->group == 16 ? PersistLayout<16>(d.njmax, b->ds.kstride, d.npair_pad, d.nlink).total : PersistLayout<32>(d.njmax, b->ds.kstride, d.npair_pad, d.nlink).total;
+        b->persist_lds_bytes = (size_t)total * sizeof(float);
+        if (b->persist_lds_bytes > 160 * 1024) b->persist = false;
+        else if (b->persist_lds_bytes > 48 * 1024) {
+            if (b->group == 16) HIPCHK(hipFuncSetAttribute((const void *)k_env_step_mf<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->persist_lds_bytes));
+            else HIPCHK(hipFuncSetAttribute((const void *)k_env_step_mf<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->persist_lds_bytes));
+        }
+    }
+    if (getenv("HSR_DEBUG")) {
+        int nb = -1;
+        if (b->solver == 2 && b->group == 16) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_solve_mf<16>, 64, b->mf_lds_bytes);
+        else if (b->solver == 1 && b->group == 16) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_solve_g<16>, 64, b->group_lds_bytes);
+        hipFuncAttributes fa;
+        if (b->solver == 2 && b->group == 16 && hipFuncGetAttributes(&fa, (const void *)k_solve_mf<16>) == hipSuccess)
+            fprintf(stderr, "[hsrsim] k_solve_mf<16>: regs %d, static LDS %zu, dyn LDS %zu, scratch %zu, maxThreads %d\n", fa.numRegs, fa.sharedSizeBytes, b->mf_lds_bytes, fa.localSizeBytes, fa.maxThreadsPerBlock);
+        fprintf(stderr, "[hsrsim] solver %d group %d: occupancy API says %d workgroups per CU\n", b->solver, b->group, nb);
+        if (b->persist && b->group == 16) {
+            int pb = -1;
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&pb, k_env_step_mf<16>, 64, b->persist_lds_bytes);
+            hipFuncAttributes fb;
+            if (hipFuncGetAttributes(&fb, (const void *)k_env_step_mf<16>) == hipSuccess)
+                fprintf(stderr, "[hsrsim] k_env_step_mf<16>: regs %d, static LDS %zu, dyn LDS %zu, scratch %zu -> %d workgroups per CU\n", fb.numRegs, fb.sharedSizeBytes, b->persist_lds_bytes, fb.localSizeBytes, pb);
+        }
+    }
     b->ds.want_soa_kin = b->solver == 0 ? 1 : 0;
     {
         const size_t kb = (size_t)64 * (b->ds.kstride + 24 * d.nlink + 1) * sizeof(float);
@@ -602,7 +631,11 @@ extern "C" int hsr_batch_step_dev(hsr_batch *b, const float *d_ctrl, int n_subst
         HIPCHK(hipEventRecord(b->ev0, st));
     }
     hipLaunchKernelGGL(k_begin_step, grid1(N), dim3(256), 0, st, b->ds, d_ctrl, b->dm.nu);
-    if (b->use_graph && !b->profiling && n_substeps > 0) {
+    if (b->persist && !b->profiling && n_substeps > 0) {
+        const int epb = 64 / b->group;
+        if (b->group == 16) hipLaunchKernelGGL(k_env_step_mf<16>, dim3((N + epb - 1) / epb), dim3(64), b->persist_lds_bytes, st, b->dm, b->ds, n_substeps, goal_body, geofence);
+        else hipLaunchKernelGGL(k_env_step_mf<32>, dim3((N + epb - 1) / epb), dim3(64), b->persist_lds_bytes, st, b->dm, b->ds, n_substeps, goal_body, geofence);
+    } else if (b->use_graph && !b->profiling && n_substeps > 0) {
         GraphKey key{n_substeps, goal_body, geofence};
         auto it = b->graphs.find(key);
         if (it == b->graphs.end()) {

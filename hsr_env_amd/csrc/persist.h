@@ -1,0 +1,227 @@
+// Persistent per-env-group kernel: one launch advances every env through a whole env-step (up to n_substeps substeps of
+// kinematics -> collision -> constraint solve -> Euler, with the per-substep goal test and early exit of HSREnv.step,
+// hsr/env.py:115-135).  Envs never interact, so there is no grid-wide synchronisation between substeps: each single-wave
+// workgroup (64/G envs, G lanes per env) loops on its own, state stays in registers/LDS, and the spread of Newton iteration
+// counts between envs averages out over the substeps instead of stalling the whole GPU at every substep boundary
+// (with per-substep kernels the mean workgroup lifetime was 110 us but the kernel lasted 244 us).
+//
+// Phases per substep and lane roles:
+//   K  kinematics + RNE recursion: lane 0 of the group walks the (<= 16-link) tree serially (kin_env, shared with k_kinematics)
+//   C  collision: lane = candidate pair (G pairs at a time): bounding culls, then box-box / plane / MPR narrowphase in the
+//      lanes whose pair survived; contacts go to the env's fixed (pair, index) slots, counts stay in LDS
+//   S  solve: the shared body of solve_mf.h (lane = dof / contact / row)
+#pragma once
+#include "collide.h"
+#include "solve_mf.h"
+
+template <int G> struct PersistLayout {
+    int R, MS, oRows, oCnt, oB, envf, oPoly, total;
+    __host__ __device__ PersistLayout(int rows, int kstride, int npair_pad, int nlink) {
+        R = rows; MS = G + 1;
+        int a = 6 * R > kstride ? 6 * R : kstride;                            // row scalars / kin record
+        oRows = 0; oCnt = (a + 3) & ~3;                                       // pair counts survive phases A-D next to the kin record
+        a = oCnt + npair_pad;
+        int b = G * MS > C2_SIZE * G ? G * MS : C2_SIZE * G;                  // inertia matrix / contact records ...
+        const int kin_tmp = 24 * nlink + 2 * G;                                // ... or link poses + recursion scratch + qpos/qvel staging
+        if (kin_tmp > b) b = kin_tmp;
+        oB = (a + 3) & ~3;
+        envf = (oB + b + 3) & ~3;
+        oPoly = envf * (64 / G);                                               // box-box polygon scratch: 8 slots of 48 floats per wave
+        total = oPoly + 8 * 48;
+    }
+};
+
+template <int G>
+__global__ void __launch_bounds__(64, 2) k_env_step_mf(DevModel m, DevState s, int n_substeps, int goal_body, float geofence) {
+    extern __shared__ __align__(16) float lds[];
+    constexpr int EPB = 64 / G;
+    const PersistLayout<G> L(m.njmax, s.kstride, m.npair_pad, m.nlink);
+    const int tid = threadIdx.x, g = tid / G, c = tid % G;
+    const int e_raw = blockIdx.x * EPB + g;
+    const bool in_range = e_raw < s.N;
+    const int e = in_range ? e_raw : 0;
+    const int N = s.N, nv = m.nv, nq = m.nq, R = L.R, MS = L.MS;
+    const int mode = 1, debug = 0;
+    float *E = lds + (size_t)g * L.envf;
+    float *rD = E + L.oRows, *rAref = rD + R, *rJar = rAref + R, *rJv = rJar + R, *rGr = rJv + R, *rDw = rGr + R;
+    float *kAng = E + L.oRows, *kLin = kAng + 3 * nv, *kAnc = kAng + 6 * nv, *lk = kAng + 9 * nv;
+    int *pcnt = reinterpret_cast<int *>(E + L.oCnt);
+    float *M = E + L.oB, *con = E + L.oB;
+    // kinematics scratch inside region B (dead before the solver writes M there)
+    float *xposL = E + L.oB, *xmatL = xposL + 3 * m.nlink, *recL = xmatL + 9 * m.nlink, *qposL = recL + 12 * m.nlink, *qvelL = qposL + G;
+    float *poly = lds + L.oPoly;
+    const bool isdof = c < nv;
+    int bad_acc = 0;
+    __shared__ int sParent[32], sMask[NLMAX];
+    __shared__ float sMass[NLMAX];
+    if (tid < nv) sParent[tid] = m.dof_parent[tid];
+    if (tid < m.nlink && tid < NLMAX) { sMask[tid] = m.link_dofmask[tid]; sMass[tid] = m.link_mass[tid]; }
+
+    // ---------------- load the env state once; it lives in registers for the whole env-step
+    float qpos_c = 0, qvel_c = 0, warm_c = 0, my_ctrl = 0, damp_c = 0;          // qpos_c: lane = qpos index; the rest: lane = dof
+    int my_type = -1, my_qadr = 0, my_quat_lane = -1, my_limited = 0, my_act = -1;
+    float lim_lo = 0, lim_hi = 0, lim_sr0 = 1, lim_sr1 = 1, lim_iw = 0, lim_si[5] = {0, 0, 0, 0, 0};
+    float act_p[6] = {0, 0, 0, 0, 0, 0};
+    bool done = !in_range || s.done[e] != 0;
+    if (c < nq) qpos_c = s.qpos[(size_t)c * N + e];
+    if (isdof) {
+        my_type = m.dof_type[c]; my_qadr = m.dof_qposadr[c]; my_limited = m.dof_limited[c]; my_act = m.dof_act[c];
+        my_quat_lane = m.link_dofadr[m.dof_link[c]] + 3;
+        damp_c = m.dof_damping[c];
+        qvel_c = s.qvel[(size_t)c * N + e]; warm_c = s.warm[(size_t)c * N + e];
+        lim_lo = m.dof_range[2 * c]; lim_hi = m.dof_range[2 * c + 1]; lim_sr0 = m.dof_solref[2 * c]; lim_sr1 = m.dof_solref[2 * c + 1];
+        lim_iw = m.dof_invweight0[c];
+#pragma unroll
+        for (int j = 0; j < 5; j++) lim_si[j] = m.dof_solimp[5 * c + j];
+        if (my_act >= 0) {
+            my_ctrl = s.ctrl[(size_t)my_act * N + e];
+            act_p[0] = m.act_kp[my_act]; act_p[1] = m.act_gear[my_act];
+            act_p[2] = m.act_ctrlrange[2 * my_act]; act_p[3] = m.act_ctrlrange[2 * my_act + 1];
+            act_p[4] = m.act_forcerange[2 * my_act]; act_p[5] = m.act_forcerange[2 * my_act + 1];
+        }
+    }
+    const v3 goal = mk3(s.mocap[e], s.mocap[N + e], s.mocap[2 * N + e]);
+    float time_e = s.time[e];
+    int nsteps_e = 0;
+    const int goal_link = (goal_body >= 0 && !m.body_mocap[goal_body]) ? m.body_link[goal_body] : -1;
+    const v3 goal_off = goal_body >= 0 ? ld3(m.body_pos, goal_body) : mk3(0, 0, 0);
+    PHASE_T0();
+
+    for (int sub = 0; sub < n_substeps; sub++) {
+        const bool valid = !done;
+        if (!__syncthreads_or(valid)) break;
+        int bad = 0;                 // per substep; only a live env's flag is kept
+        // ---------------- K: kinematics of this env by lane 0 of its group, on LDS views
+        qposL[c] = qpos_c; qvelL[c] = qvel_c;
+        __syncthreads();
+        if (valid && c == 0) {
+            kin_env(m, View{qposL, 1}, View{qvelL, 1}, View{xposL, 1}, View{xmatL, 1}, View{kAng, 1}, View{kLin, 1}, View{kAnc, 1}, View{lk, 1},
+                    View{recL, 1}, View{recL + 3 * m.nlink, 1}, View{recL + 6 * m.nlink, 1}, View{recL + 9 * m.nlink, 1});
+        }
+        __syncthreads();
+        qpos_c = qposL[c];                                   // mj_kinematics normalises free-joint quaternions in place
+        if (!(fabsf(qpos_c) <= 1e10f) || !(fabsf(qvel_c) <= 1e10f)) bad = 1;
+        // a-3 goal test uses the xpos of this substep's forward pass
+        bool reach = false;
+        if (goal_body >= 0) {
+            v3 bp = goal;
+            if (goal_link >= 0) bp = mk3(xposL[3 * goal_link], xposL[3 * goal_link + 1], xposL[3 * goal_link + 2]) + mulmv(View{xmatL, 1}.getm(goal_link), goal_off);
+            reach = norm(bp - goal) < geofence;
+        }
+        // link poses of an env's last substep go to global memory (sim.data.get_body_xpos after step(), hsr/env.py:144)
+        if (valid && (sub == n_substeps - 1 || reach)) {
+            for (int i = c; i < 3 * m.nlink; i += G) s.xpos[(size_t)i * N + e] = xposL[i];
+            for (int i = c; i < 9 * m.nlink; i += G) s.xmat[(size_t)i * N + e] = xmatL[i];
+        }
+        // ---------------- C: collision, lane = candidate pair
+        {
+            float *cong = s.con + (size_t)e * m.nslot * 8;
+            for (int p0 = 0; p0 < m.npair; p0 += G) {
+                const int p = p0 + c;
+                const bool have = valid && p < m.npair;
+                const int ps = have ? p : 0;
+                const int g1 = m.pair_geom1[ps], g2 = m.pair_geom2[ps];
+                Geom G1 = load_geom_v(m, View{xposL, 1}, View{xmatL, 1}, g1), G2 = load_geom_v(m, View{xposL, 1}, View{xmatL, 1}, g2);
+                const bool pass = have && pair_cull(m, G1, G2, g1, g2);
+                ContactOut out;
+                out.con = cong; out.slot = m.pair_slot[ps]; out.maxcnt = m.pair_slot[ps + 1] - m.pair_slot[ps]; out.cnt = 0;
+                const int fn = m.pair_fn[ps];
+                if (pass) {
+                    if (G1.type == GEOM_MESH) G1.verts = m.mesh_vert4 + m.geom_meshadr[g1];
+                    if (G2.type == GEOM_MESH) G2.verts = m.mesh_vert4 + m.geom_meshadr[g2];
+                    if (fn == FN_PLANE_BOX) collide_plane_box(G1, G2, out);
+                    else if (fn == FN_PLANE_CONVEX) collide_plane_convex(G1, G2, out);
+                    else if (fn == FN_CONVEX) {
+                        float *sx = s.sepax + (size_t)(3 * p) * N + e;
+                        const v3 d = mk3(sx[0], sx[N], sx[2 * (size_t)N]);
+                        bool still = false;
+                        if (d.x != 0.f || d.y != 0.f || d.z != 0.f) still = dot(support(G1, d) - support(G2, -d), d) < -1e-7f;
+                        if (!still) {
+                            float depth; v3 dir, pos, sep;
+                            int nsup = 0;
+                            if (mpr_penetration(G1, G2, m.mpr_tolerance, m.mpr_iterations, depth, dir, pos, sep, nsup)) { out.add(pos, dir, -depth); sep = mk3(0, 0, 0); }
+                            sx[0] = sep.x; sx[N] = sep.y; sx[2 * (size_t)N] = sep.z;
+                        }
+                    }
+                }
+                // box-box needs LDS polygon scratch: at most 8 lanes of the wave run it at a time
+                {
+                    const bool bb = pass && fn == FN_BOX_BOX;
+                    unsigned long long pend = __ballot(bb);
+                    while (pend) {
+                        const int rank = __popcll(pend & ((1ull << tid) - 1ull));
+                        const bool mine = bb && ((pend >> tid) & 1ull) && rank < 8;
+                        if (mine) collide_box_box_slot(G1, G2, out, poly + 48 * rank);
+                        // retire the (up to) 8 lowest pending lanes
+                        unsigned long long t = pend; int k = 0;
+                        while (t && k < 8) { t &= t - 1; k++; }
+                        pend = t;
+                    }
+                }
+                if (p < m.npair) pcnt[p] = out.cnt;
+            }
+        }
+        __threadfence_block();       // contact records written to global by other lanes of this workgroup
+        __syncthreads();
+        // ---------------- S: dynamics + constraint solve + Euler (shared body)
+        constexpr int MAXCH = 256 / G;
+        int cnt_ch[MAXCH];
+#pragma unroll
+        for (int ch = 0; ch < MAXCH; ch++) { const int p = ch * G + c; cnt_ch[ch] = (valid && p < m.npair) ? pcnt[p] : 0; }
+        // per-dof view of qpos (scalar joints: their own coordinate; free joints: lin dofs their coordinate)
+        float my_q = 0;
+        q4 quat0; quat0.w = 1; quat0.x = quat0.y = quat0.z = 0;
+        if (isdof) {
+            my_q = qposL[my_qadr];
+            if (c == my_quat_lane && my_type == DOF_FREE_ANG) { quat0.w = qposL[my_qadr]; quat0.x = qposL[my_qadr + 1]; quat0.y = qposL[my_qadr + 2]; quat0.z = qposL[my_qadr + 3]; }
+        }
+        __syncthreads();             // qposL / link poses are read; region B may now be reused by the solver
+        {
+#define SOLVE_STORE_DIAG false
+#include "solve_body.inc"
+#undef SOLVE_STORE_DIAG
+            // ---------------- integrate (a-2.7) in registers; qpos is redistributed through LDS (lane = qpos index)
+            const float v1 = __shfl_down(vnew, 1, G), v2 = __shfl_down(vnew, 2, G);
+            __syncthreads();
+            float *qn = rJv;             // any free row array: the solver is finished with it
+            if (valid && isdof) {
+                if (my_type == DOF_SLIDE || my_type == DOF_HINGE || my_type == DOF_FREE_LIN) qn[my_qadr] = my_q + h * vnew;
+                else if (c == my_quat_lane) {
+                    const v3 w = mk3(vnew, v1, v2);
+                    const float wn = norm(w), angle = wn * h;
+                    q4 q = quat0;
+                    if (angle > 0) {
+                        const v3 ax = w * (1.0f / wn);
+                        float sn, cs;
+                        sincosf(0.5f * angle, &sn, &cs);
+                        q4 qr;
+                        qr.w = cs; qr.x = ax.x * sn; qr.y = ax.y * sn; qr.z = ax.z * sn;
+                        q = qnormalized(qmul(quat0, qr));
+                    }
+                    qn[my_qadr] = q.w; qn[my_qadr + 1] = q.x; qn[my_qadr + 2] = q.y; qn[my_qadr + 3] = q.z;
+                }
+            }
+            __syncthreads();
+            if (valid) {
+                if (c < nq) qpos_c = qn[c];
+                qvel_c = vnew; warm_c = qacc_c;
+                time_e += h; nsteps_e += 1;
+                if (bad) bad_acc = 1;
+                if (reach) done = true;          // a-4: latch; the env skips the remaining substeps
+            }
+            __syncthreads();
+        }
+    }
+    // ---------------- write the state back (struct-of-arrays)
+    if (in_range && !(s.done[e] != 0 && nsteps_e == 0)) {
+        if (c < nq) s.qpos[(size_t)c * N + e] = qpos_c;
+        if (isdof) { s.qvel[(size_t)c * N + e] = qvel_c; s.warm[(size_t)c * N + e] = warm_c; }
+        const float bsum = gsum<G>((float)bad_acc);
+        if (c == 0) {
+            s.time[e] = time_e; s.nsteps[e] = s.nsteps[e] + nsteps_e;
+            if (bsum > 0) s.bad[e] = 1;
+            if (done) s.done[e] = 1;
+        }
+    }
+    PHASE_FLUSH();
+}

@@ -25,9 +25,9 @@ __device__ __forceinline__ unsigned long long stamp_() {
     __builtin_amdgcn_sched_barrier(0);
     return t;
 }
-#define PHASE_T0() unsigned long long pt_[20] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long t_prev_ = stamp_()
+#define PHASE_T0() unsigned long long pt_[20] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long t_prev_ = stamp_(); const unsigned long long t_first_ = t_prev_, r_first_ = __builtin_amdgcn_s_memrealtime()
 #define PHASE(idx) do { const unsigned long long t_now_ = stamp_(); pt_[idx] += t_now_ - t_prev_; t_prev_ = t_now_; } while (0)
-#define PHASE_FLUSH() do { if (tid == 0) { _Pragma("unroll") for (int i_ = 0; i_ < 20; i_++) atomicAdd(&s.phase_cyc[i_], pt_[i_]); } } while (0)
+#define PHASE_FLUSH() do { if (tid == 0) { atomicAdd(&s.phase_cyc[26], stamp_() - t_first_); atomicAdd(&s.phase_cyc[27], __builtin_amdgcn_s_memrealtime() - r_first_); _Pragma("unroll") for (int i_ = 0; i_ < 20; i_++) atomicAdd(&s.phase_cyc[i_], pt_[i_]); } } while (0)
 #else
 #define PHASE_T0() do {} while (0)
 #define PHASE(idx) do {} while (0)

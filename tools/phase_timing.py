@@ -31,3 +31,4 @@ print('total cyc/block/substep', tot / (2048 * 300))
 w = np.array(list(buf), dtype=np.float64)
 print('MPR: calls/substep %.1f  cache hits/substep %.1f  supports/call %.2f  max supports in a call %d  calls with >20 supports per substep %.2f' % (
     w[22] / 300, w[23] / 300, w[20] / max(w[22], 1), w[21], w[24] / 300))
+print('in-kernel clock: %.2f GHz (s_memtime / s_memrealtime * 100 MHz); mean block lifetime %.1f us' % (w[26] / max(w[27], 1) * 0.1, w[27] / (2048 * 300) / 100.0))
