@@ -84,6 +84,7 @@ def main():
     ap.add_argument("--config", default="cfg3")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-persistent", action="store_true", help="per-substep kernels instead of the persistent env-step kernel")
     args = ap.parse_args()
 
     import torch
@@ -116,6 +117,9 @@ def main():
     sim = BatchSim(m, n, device=local_rank)
     if args.no_graph:
         sim.set_graph(False)
+    if args.no_persistent:
+        sim.set_persistent(False)
+    persistent = sim.is_persistent()
     sim.reset(qpos0=q0, mocap=goal)
     # everything the timed region consumes is resident in HBM before it starts
     d_ctrl = [torch.from_numpy(c).to(dev) for c in ctrl_host]
@@ -170,18 +174,25 @@ def main():
     sim.sync()
     tot_ms, k_ms, k_n = sim.last_timing()
     sim.set_profiling(False)
-    names = ["k_kinematics", "k_collide", "k_solve"]
-    dom = int(np.argmax(k_ms))
+    if persistent:
+        # one launch = one env-step of every env (kinematics + collision + solve + integrate, 300 substeps in-kernel)
+        names = ["-", "-", "k_env_step_mf"]
+        dom = 2
+        units_per_launch = STEPS_PER_ACTION
+    else:
+        names = ["k_kinematics", "k_cull+k_narrow", "k_solve_mf"]
+        dom = int(np.argmax(k_ms))
+        units_per_launch = 1
     avg_us = 1e3 * k_ms[dom] / max(k_n[dom], 1)
     # algorithmic bytes: fp32 state stream per substep per env = 4*(2nq+2nv+nu+3) (SURVEY.md 8d / BASELINE.md 3)
     bytes_per_substep_env = 4 * (2 * m.nq + 2 * m.nv + m.nu + 3)
-    bytes_per_launch = bytes_per_substep_env * n
+    bytes_per_launch = bytes_per_substep_env * n * units_per_launch + (4 * (m.nq + m.nv) + 5) * n * (1 if persistent else 0)
     achieved = bytes_per_launch / (avg_us * 1e-6) / 1e9
     traffic = None
     pmc = ROOT / "profiles" / "pmc_summary.json"
     if pmc.exists():
         try:
-            traffic = json.loads(pmc.read_text()).get(names[dom], {}).get("hbm_bytes_per_launch")
+            traffic = json.loads(pmc.read_text()).get(names[dom].split("<")[0], {}).get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
     value = world * n * K / dt
@@ -198,11 +209,13 @@ def main():
                    "envs_per_gpu": n, "global_envs": world * n, "substeps_per_env_step": STEPS_PER_ACTION,
                    "mean_substeps_executed": mean_substeps, "done_fraction": float(dones.item()) / (n * K),
                    "parallelism": f"env-shard x{world}" + (" + all-gather(obs,reward,done)" if world > 1 else ""),
-                   "substeps_per_s": value * mean_substeps, "hipgraph": not args.no_graph, "bad_envs": int(bad.sum())},
+                   "substeps_per_s": value * mean_substeps, "persistent_kernel": persistent, "hipgraph": (not args.no_graph) and not persistent,
+                   "bad_envs": int(bad.sum())},
         "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                      "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_us": avg_us,
-                     "kernel_ms_per_env_step": dict(zip(names, k_ms)), "launches_per_env_step": dict(zip(names, k_n)),
+                     "kernel_ms_per_env_step": {nm: ms for nm, ms in zip(names, k_ms) if nm != "-"},
+                     "launches_per_env_step": {nm: k for nm, k in zip(names, k_n) if nm != "-"},
                      "note": "state stays L2/MALL-resident; the path is FP32-VALU/latency bound, not HBM bound (SURVEY.md 8d)"},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -10,122 +10,136 @@
 // velocity part).  All arrays are Views so that the same code serves the one-lane-per-env kernel (LDS tile per lane)
 // and the persistent per-env-group kernel (LDS record of the group).  Outputs: link poses, world dof axes/anchors,
 // per-link com(3) Iworld(6) F(3) N(3) in ld; lw/lvo/lal/lao are scratch (12 floats per link).
-__device__ void kin_env(const DevModel &m, View qpos, View qvel, View xpos, View xmat, View ang, View lin, View anc, View ld,
-                        View lw, View lvo, View lal, View lao) {
+// pose of link l from its (already computed) parent and its joint coordinates; also the world axes of its dofs
+__device__ __forceinline__ void kin_link_pose(const DevModel &m, int l, View qpos, View xpos, View xmat, View ang, View lin, View anc) {
+    v3 pos;
+    m3 mat;
+    const int d0 = m.link_dofadr[l], dn = m.link_dofnum[l];
+    if (m.link_free[l]) {
+        const int a = m.link_qposadr[l];
+        pos = mk3(qpos[a], qpos[a + 1], qpos[a + 2]);
+        q4 q;
+        q.w = qpos[a + 3]; q.x = qpos[a + 4]; q.y = qpos[a + 5]; q.z = qpos[a + 6];
+        q = qnormalized(q);                                  // mj_kinematics normalises in place
+        qpos[a + 3] = q.w; qpos[a + 4] = q.x; qpos[a + 5] = q.y; qpos[a + 6] = q.z;
+        mat = q2m(q);
+        for (int k = 0; k < 3; k++) {
+            lin.set3(d0 + k, mk3(k == 0, k == 1, k == 2));
+            ang.set3(d0 + k, mk3(0, 0, 0));
+            anc.set3(d0 + k, pos);
+            ang.set3(d0 + 3 + k, col(mat, k));
+            lin.set3(d0 + 3 + k, mk3(0, 0, 0));
+            anc.set3(d0 + 3 + k, pos);
+        }
+    } else {
+        const int p = m.link_parent[l];
+        const m3 Rp = xmat.getm(p);
+        pos = xpos.get3(p) + mulmv(Rp, ld3(m.link_pos, l));
+        mat = mulmm(Rp, ldm(m.link_mat, l));
+        for (int k = d0; k < d0 + dn; k++) {
+            const float q = qpos[m.dof_qposadr[k]];
+            const v3 ax = ld3(m.dof_axis, k);
+            if (m.dof_type[k] == DOF_SLIDE) {
+                pos = pos + mulmv(mat, ax) * q;
+            } else {
+                const v3 jp = ld3(m.dof_pos, k);
+                const v3 anchor = pos + mulmv(mat, jp);
+                float sn, cs;
+                sincosf(0.5f * q, &sn, &cs);
+                q4 qr;
+                qr.w = cs; qr.x = ax.x * sn; qr.y = ax.y * sn; qr.z = ax.z * sn;
+                mat = mulmm(mat, q2m(qr));
+                pos = anchor - mulmv(mat, jp);
+            }
+        }
+        for (int k = d0; k < d0 + dn; k++) {
+            const v3 ax = mulmv(mat, ld3(m.dof_axis, k));
+            if (m.dof_type[k] == DOF_SLIDE) {
+                lin.set3(k, ax); ang.set3(k, mk3(0, 0, 0)); anc.set3(k, pos);
+            } else {
+                ang.set3(k, ax); lin.set3(k, mk3(0, 0, 0)); anc.set3(k, pos + mulmv(mat, ld3(m.dof_pos, k)));
+            }
+        }
+    }
+    xpos.set3(l, pos);
+    xmat.setm(l, mat);
+}
+
+// velocity / bias acceleration (qacc = 0) of link l from its parent's, and the per-link wrench of mj_rne:
+// F = m (a_com - g), N = I alpha + w x I w  (consumed by the solver as bias = J^T [F; N])
+__device__ __forceinline__ void kin_link_dyn(const DevModel &m, int l, View qvel, View xpos, View xmat, View ang, View lin, View anc, View ld,
+                                             View lw, View lvo, View lal, View lao) {
+    const int d0 = m.link_dofadr[l];
+    const m3 R = xmat.getm(l);
+    const v3 xl = xpos.get3(l);
+    v3 w, vo, al, ao;
+    if (m.link_free[l]) {
+        vo = mk3(qvel[d0], qvel[d0 + 1], qvel[d0 + 2]);
+        w = mulmv(R, mk3(qvel[d0 + 3], qvel[d0 + 4], qvel[d0 + 5]));
+        al = mk3(0, 0, 0); ao = mk3(0, 0, 0);
+    } else {
+        const int p = m.link_parent[l];
+        const v3 wp = lw.get3(p), vop = lvo.get3(p), alp = lal.get3(p), aop = lao.get3(p);
+        const v3 r = xl - xpos.get3(p);
+        w = wp; al = alp;
+        vo = vop + cross(wp, r);
+        ao = aop + cross(alp, r) + cross(wp, cross(wp, r));
+        for (int k = d0; k < d0 + m.link_dofnum[l]; k++) {
+            const float qd = qvel[k];
+            if (m.dof_type[k] == DOF_SLIDE) {
+                const v3 sx = lin.get3(k);
+                vo = vo + sx * qd;
+                ao = ao + cross(wp, sx) * (2 * qd);
+            } else {
+                const v3 a = ang.get3(k);
+                const v3 rho = xl - anc.get3(k), rc = r - rho;
+                const v3 wl = w + a * qd, all = al + cross(w, a) * qd;
+                const v3 ac = aop + cross(alp, rc) + cross(wp, cross(wp, rc));
+                const v3 vc = vop + cross(wp, rc);
+                ao = ac + cross(all, rho) + cross(wl, cross(wl, rho));
+                vo = vc + cross(wl, rho);
+                w = wl; al = all;
+            }
+        }
+    }
+    lw.set3(l, w); lvo.set3(l, vo); lal.set3(l, al); lao.set3(l, ao);
+    const float *li = m.link_inertia + 6 * l;
+    m3 Il, Rt;
+    Il.a[0] = li[0]; Il.a[1] = li[3]; Il.a[2] = li[4]; Il.a[3] = li[3]; Il.a[4] = li[1]; Il.a[5] = li[5]; Il.a[6] = li[4]; Il.a[7] = li[5]; Il.a[8] = li[2];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) Rt.a[3 * i + j] = R.a[3 * j + i];
+    const m3 I = mulmm(mulmm(R, Il), Rt);
+    const v3 com = xl + mulmv(R, ld3(m.link_com, l)), rc = com - xl;
+    const v3 acom = ao + cross(al, rc) + cross(w, cross(w, rc));
+    const v3 F = (acom - mk3(0, 0, m.gravz)) * m.link_mass[l];
+    const v3 Nt = mulmv(I, al) + cross(w, mulmv(I, w));
+    const int b = 15 * l;
+    ld[b] = com.x; ld[b + 1] = com.y; ld[b + 2] = com.z;
+    ld[b + 3] = I.a[0]; ld[b + 4] = I.a[4]; ld[b + 5] = I.a[8]; ld[b + 6] = I.a[1]; ld[b + 7] = I.a[2]; ld[b + 8] = I.a[5];
+    ld[b + 9] = F.x; ld[b + 10] = F.y; ld[b + 11] = F.z; ld[b + 12] = Nt.x; ld[b + 13] = Nt.y; ld[b + 14] = Nt.z;
+}
+
+__device__ __forceinline__ void kin_link0(View xpos, View xmat, View ld, View lw, View lvo, View lal, View lao) {
     m3 I;
 #pragma unroll
     for (int k = 0; k < 9; k++) I.a[k] = (k % 4 == 0) ? 1.f : 0.f;
     xpos.set3(0, mk3(0, 0, 0));
     xmat.setm(0, I);
-    for (int l = 1; l < m.nlink; l++) {
-        v3 pos;
-        m3 mat;
-        const int d0 = m.link_dofadr[l], dn = m.link_dofnum[l];
-        if (m.link_free[l]) {
-            const int a = m.link_qposadr[l];
-            pos = mk3(qpos[a], qpos[a + 1], qpos[a + 2]);
-            q4 q;
-            q.w = qpos[a + 3]; q.x = qpos[a + 4]; q.y = qpos[a + 5]; q.z = qpos[a + 6];
-            q = qnormalized(q);                                  // mj_kinematics normalises in place
-            qpos[a + 3] = q.w; qpos[a + 4] = q.x; qpos[a + 5] = q.y; qpos[a + 6] = q.z;
-            mat = q2m(q);
-            for (int k = 0; k < 3; k++) {
-                lin.set3(d0 + k, mk3(k == 0, k == 1, k == 2));
-                ang.set3(d0 + k, mk3(0, 0, 0));
-                anc.set3(d0 + k, pos);
-                ang.set3(d0 + 3 + k, col(mat, k));
-                lin.set3(d0 + 3 + k, mk3(0, 0, 0));
-                anc.set3(d0 + 3 + k, pos);
-            }
-        } else {
-            const int p = m.link_parent[l];
-            const m3 Rp = xmat.getm(p);
-            pos = xpos.get3(p) + mulmv(Rp, ld3(m.link_pos, l));
-            mat = mulmm(Rp, ldm(m.link_mat, l));
-            for (int k = d0; k < d0 + dn; k++) {
-                const float q = qpos[m.dof_qposadr[k]];
-                const v3 ax = ld3(m.dof_axis, k);
-                if (m.dof_type[k] == DOF_SLIDE) {
-                    pos = pos + mulmv(mat, ax) * q;
-                } else {
-                    const v3 jp = ld3(m.dof_pos, k);
-                    const v3 anchor = pos + mulmv(mat, jp);
-                    float sn, cs;
-                    sincosf(0.5f * q, &sn, &cs);
-                    q4 qr;
-                    qr.w = cs; qr.x = ax.x * sn; qr.y = ax.y * sn; qr.z = ax.z * sn;
-                    mat = mulmm(mat, q2m(qr));
-                    pos = anchor - mulmv(mat, jp);
-                }
-            }
-            for (int k = d0; k < d0 + dn; k++) {
-                const v3 ax = mulmv(mat, ld3(m.dof_axis, k));
-                if (m.dof_type[k] == DOF_SLIDE) {
-                    lin.set3(k, ax); ang.set3(k, mk3(0, 0, 0)); anc.set3(k, pos);
-                } else {
-                    ang.set3(k, ax); lin.set3(k, mk3(0, 0, 0)); anc.set3(k, pos + mulmv(mat, ld3(m.dof_pos, k)));
-                }
-            }
-        }
-        xpos.set3(l, pos);
-        xmat.setm(l, mat);
-    }
-    // ---- link velocities / bias accelerations (qacc = 0) and the per-link wrench of mj_rne:
-    //      F = m (a_com - g), N = I alpha + w x I w  (consumed by the solve kernel as bias = J^T [F; N])
     lw.set3(0, mk3(0, 0, 0)); lvo.set3(0, mk3(0, 0, 0)); lal.set3(0, mk3(0, 0, 0)); lao.set3(0, mk3(0, 0, 0));
     for (int k = 0; k < 15; k++) ld[k] = 0;
-    for (int l = 1; l < m.nlink; l++) {
-        const int d0 = m.link_dofadr[l];
-        const m3 R = xmat.getm(l);
-        const v3 xl = xpos.get3(l);
-        v3 w, vo, al, ao;
-        if (m.link_free[l]) {
-            vo = mk3(qvel[d0], qvel[d0 + 1], qvel[d0 + 2]);
-            w = mulmv(R, mk3(qvel[d0 + 3], qvel[d0 + 4], qvel[d0 + 5]));
-            al = mk3(0, 0, 0); ao = mk3(0, 0, 0);
-        } else {
-            const int p = m.link_parent[l];
-            const v3 wp = lw.get3(p), vop = lvo.get3(p), alp = lal.get3(p), aop = lao.get3(p);
-            const v3 r = xl - xpos.get3(p);
-            w = wp; al = alp;
-            vo = vop + cross(wp, r);
-            ao = aop + cross(alp, r) + cross(wp, cross(wp, r));
-            for (int k = d0; k < d0 + m.link_dofnum[l]; k++) {
-                const float qd = qvel[k];
-                if (m.dof_type[k] == DOF_SLIDE) {
-                    const v3 sx = lin.get3(k);
-                    vo = vo + sx * qd;
-                    ao = ao + cross(wp, sx) * (2 * qd);
-                } else {
-                    const v3 a = ang.get3(k);
-                    const v3 rho = xl - anc.get3(k), rc = r - rho;
-                    const v3 wl = w + a * qd, all = al + cross(w, a) * qd;
-                    const v3 ac = aop + cross(alp, rc) + cross(wp, cross(wp, rc));
-                    const v3 vc = vop + cross(wp, rc);
-                    ao = ac + cross(all, rho) + cross(wl, cross(wl, rho));
-                    vo = vc + cross(wl, rho);
-                    w = wl; al = all;
-                }
-            }
-        }
-        lw.set3(l, w); lvo.set3(l, vo); lal.set3(l, al); lao.set3(l, ao);
-        const float *li = m.link_inertia + 6 * l;
-        m3 Il, Rt;
-        Il.a[0] = li[0]; Il.a[1] = li[3]; Il.a[2] = li[4]; Il.a[3] = li[3]; Il.a[4] = li[1]; Il.a[5] = li[5]; Il.a[6] = li[4]; Il.a[7] = li[5]; Il.a[8] = li[2];
-#pragma unroll
-        for (int i = 0; i < 3; i++)
-#pragma unroll
-            for (int j = 0; j < 3; j++) Rt.a[3 * i + j] = R.a[3 * j + i];
-        const m3 I = mulmm(mulmm(R, Il), Rt);
-        const v3 com = xl + mulmv(R, ld3(m.link_com, l)), rc = com - xl;
-        const v3 acom = ao + cross(al, rc) + cross(w, cross(w, rc));
-        const v3 F = (acom - mk3(0, 0, m.gravz)) * m.link_mass[l];
-        const v3 Nt = mulmv(I, al) + cross(w, mulmv(I, w));
-        const int b = 15 * l;
-        ld[b] = com.x; ld[b + 1] = com.y; ld[b + 2] = com.z;
-        ld[b + 3] = I.a[0]; ld[b + 4] = I.a[4]; ld[b + 5] = I.a[8]; ld[b + 6] = I.a[1]; ld[b + 7] = I.a[2]; ld[b + 8] = I.a[5];
-        ld[b + 9] = F.x; ld[b + 10] = F.y; ld[b + 11] = F.z; ld[b + 12] = Nt.x; ld[b + 13] = Nt.y; ld[b + 14] = Nt.z;
-    }
+}
+
+// Kinematics + RNE velocity recursion of ONE env, serial over its links (mj_kinematics, mj_comPos, mj_comVel / velocity
+// part of mj_rne).  All arrays are Views: the one-lane-per-env kernel passes its LDS tile, the persistent kernel runs the
+// same per-link functions with lane = link, one tree level at a time.  Outputs: link poses, world dof axes / anchors,
+// per-link com(3) Iworld(6) F(3) N(3) in ld; lw/lvo/lal/lao are scratch (3 floats per link each).
+__device__ void kin_env(const DevModel &m, View qpos, View qvel, View xpos, View xmat, View ang, View lin, View anc, View ld,
+                        View lw, View lvo, View lal, View lao) {
+    kin_link0(xpos, xmat, ld, lw, lvo, lal, lao);
+    for (int l = 1; l < m.nlink; l++) kin_link_pose(m, l, qpos, xpos, xmat, ang, lin, anc);
+    for (int l = 1; l < m.nlink; l++) kin_link_dyn(m, l, qvel, xpos, xmat, ang, lin, anc, ld, lw, lvo, lal, lao);
 }
 
 // ------------------------------------------------------------------ kinematics (a-2.1)
@@ -216,14 +230,17 @@ __device__ __forceinline__ v3 support(const Geom &G, v3 dir) {
         float bA = -3.0e38f, bB = -3.0e38f;
         int iA = 0, iB = 1;
         int i = 0;
-        for (; i + 4 <= G.nvert; i += 4) {
-            const float4 a = G.verts[i], b = G.verts[i + 1], c4 = G.verts[i + 2], d = G.verts[i + 3];
-            const float ta = a.x * dl.x + a.y * dl.y + a.z * dl.z, tb = b.x * dl.x + b.y * dl.y + b.z * dl.z;
-            const float tc = c4.x * dl.x + c4.y * dl.y + c4.z * dl.z, td = d.x * dl.x + d.y * dl.y + d.z * dl.z;
-            iA = ta > bA ? i : iA; bA = fmaxf(bA, ta);
-            iB = tb > bB ? i + 1 : iB; bB = fmaxf(bB, tb);
-            iA = tc > bA ? i + 2 : iA; bA = fmaxf(bA, tc);
-            iB = td > bB ? i + 3 : iB; bB = fmaxf(bB, td);
+        for (; i + 8 <= G.nvert; i += 8) {
+            // 8 vertex loads in flight before the first use (the table may live in global memory / L1)
+            float4 q[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) q[u] = G.verts[i + u];
+#pragma unroll
+            for (int u = 0; u < 8; u += 2) {
+                const float ta = q[u].x * dl.x + q[u].y * dl.y + q[u].z * dl.z, tb = q[u + 1].x * dl.x + q[u + 1].y * dl.y + q[u + 1].z * dl.z;
+                iA = ta > bA ? i + u : iA; bA = fmaxf(bA, ta);
+                iB = tb > bB ? i + u + 1 : iB; bB = fmaxf(bB, tb);
+            }
         }
         for (; i < G.nvert; i++) {
             const float4 a = G.verts[i];

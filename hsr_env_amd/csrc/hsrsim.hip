@@ -351,6 +351,15 @@ extern "C" int hsr_batch_create(const hsr_model *m, int n_envs, int device_id, h
     UI(act_dof) UF(act_gear) UF(act_kp) UF(act_ctrlrange) UF(act_forcerange)
 #undef UI
 #undef UF
+    {   // tree depth of every link: the persistent kernel walks the tree level by level with lane = link
+        const int *lp = m->i32("link_parent");
+        std::vector<int> dep(std::max(d.nlink, 1), 0);
+        d.maxdepth = 0;
+        for (int l = 1; l < d.nlink; l++) { dep[l] = dep[lp[l]] + 1; d.maxdepth = std::max(d.maxdepth, dep[l]); }
+        int *dd; if ((rc = dalloc(b, &dd, dep.size()))) return rc;
+        HIPCHK(hipMemcpy(dd, dep.data(), dep.size() * sizeof(int), hipMemcpyHostToDevice));
+        d.link_depth = dd;
+    }
     {   // hull vertices as float4
         size_t cnt = 0;
         const double *mv = m->f64("mesh_vert", &cnt);
@@ -517,6 +526,8 @@ extern "C" void *hsr_batch_stream(const hsr_batch *b) { return (void *)b->stream
 extern "C" int hsr_batch_sync(hsr_batch *b) { HIPCHK(hipSetDevice(b->device)); HIPCHK(hipStreamSynchronize(b->stream)); return HSR_OK; }
 extern "C" int hsr_batch_set_profiling(hsr_batch *b, int on) { b->profiling = on != 0; return HSR_OK; }
 extern "C" int hsr_batch_set_graph(hsr_batch *b, int on) { b->use_graph = on != 0; return HSR_OK; }
+extern "C" int hsr_batch_set_persistent(hsr_batch *b, int on) { b->persist = on != 0 && b->solver == 2 && b->persist_lds_bytes > 0 && b->persist_lds_bytes <= 160 * 1024; return b->persist ? 1 : 0; }
+extern "C" int hsr_batch_is_persistent(const hsr_batch *b) { return b->persist ? 1 : 0; }
 
 // one substep = 3 launches on the batch stream
 static void launch_substep(hsr_batch *b, int mode, int goal_body, float geofence, int debug, hipStream_t st, bool timed) {
@@ -631,10 +642,12 @@ extern "C" int hsr_batch_step_dev(hsr_batch *b, const float *d_ctrl, int n_subst
         HIPCHK(hipEventRecord(b->ev0, st));
     }
     hipLaunchKernelGGL(k_begin_step, grid1(N), dim3(256), 0, st, b->ds, d_ctrl, b->dm.nu);
-    if (b->persist && !b->profiling && n_substeps > 0) {
+    if (b->persist && n_substeps > 0) {
         const int epb = 64 / b->group;
+        if (b->profiling) { hipEvent_t ev; for (int k = 0; k < 3; k++) { hipEventCreate(&ev); hipEventRecord(ev, st); b->kev.push_back(ev); } }
         if (b->group == 16) hipLaunchKernelGGL(k_env_step_mf<16>, dim3((N + epb - 1) / epb), dim3(64), b->persist_lds_bytes, st, b->dm, b->ds, n_substeps, goal_body, geofence);
         else hipLaunchKernelGGL(k_env_step_mf<32>, dim3((N + epb - 1) / epb), dim3(64), b->persist_lds_bytes, st, b->dm, b->ds, n_substeps, goal_body, geofence);
+        if (b->profiling) { hipEvent_t ev; hipEventCreate(&ev); hipEventRecord(ev, st); b->kev.push_back(ev); }   // slots 0,1 empty; slot 2 = the persistent kernel
     } else if (b->use_graph && !b->profiling && n_substeps > 0) {
         GraphKey key{n_substeps, goal_body, geofence};
         auto it = b->graphs.find(key);

@@ -14,7 +14,8 @@ struct DevModel {
     int iterations, ls_iterations, mpr_iterations, any_damping;
     const int *link_parent, *link_dofadr, *link_dofnum, *link_qposadr, *link_free;
     const float *link_pos, *link_mat, *link_mass, *link_com, *link_inertia;
-    const int *link_dofmask;
+    const int *link_dofmask, *link_depth;   // depth of a link in the kinematic tree (world = 0)
+    int maxdepth;
     const int *dof_link, *dof_type, *dof_parent, *dof_qposadr, *dof_limited;
     const float *dof_axis, *dof_pos, *dof_damping, *dof_invweight0, *dof_range, *dof_solref, *dof_solimp;
     const int *body_link, *body_mocap;

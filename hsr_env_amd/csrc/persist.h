@@ -52,34 +52,16 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(DevModel m, DevState s, i
     float *poly = lds + L.oPoly;
     const bool isdof = c < nv;
     int bad_acc = 0;
-    __shared__ int sParent[32], sMask[NLMAX];
+    __shared__ int sParent[32], sMask[NLMAX], sDepth[NLMAX];
     __shared__ float sMass[NLMAX];
     if (tid < nv) sParent[tid] = m.dof_parent[tid];
-    if (tid < m.nlink && tid < NLMAX) { sMask[tid] = m.link_dofmask[tid]; sMass[tid] = m.link_mass[tid]; }
+    if (tid < m.nlink && tid < NLMAX) { sMask[tid] = m.link_dofmask[tid]; sMass[tid] = m.link_mass[tid]; sDepth[tid] = m.link_depth[tid]; }
 
     // ---------------- load the env state once; it lives in registers for the whole env-step
-    float qpos_c = 0, qvel_c = 0, warm_c = 0, my_ctrl = 0, damp_c = 0;          // qpos_c: lane = qpos index; the rest: lane = dof
-    int my_type = -1, my_qadr = 0, my_quat_lane = -1, my_limited = 0, my_act = -1;
-    float lim_lo = 0, lim_hi = 0, lim_sr0 = 1, lim_sr1 = 1, lim_iw = 0, lim_si[5] = {0, 0, 0, 0, 0};
-    float act_p[6] = {0, 0, 0, 0, 0, 0};
+    float qpos_c = 0, qvel_c = 0, warm_c = 0;          // qpos_c: lane = qpos index; qvel_c / warm_c: lane = dof
     bool done = !in_range || s.done[e] != 0;
     if (c < nq) qpos_c = s.qpos[(size_t)c * N + e];
-    if (isdof) {
-        my_type = m.dof_type[c]; my_qadr = m.dof_qposadr[c]; my_limited = m.dof_limited[c]; my_act = m.dof_act[c];
-        my_quat_lane = m.link_dofadr[m.dof_link[c]] + 3;
-        damp_c = m.dof_damping[c];
-        qvel_c = s.qvel[(size_t)c * N + e]; warm_c = s.warm[(size_t)c * N + e];
-        lim_lo = m.dof_range[2 * c]; lim_hi = m.dof_range[2 * c + 1]; lim_sr0 = m.dof_solref[2 * c]; lim_sr1 = m.dof_solref[2 * c + 1];
-        lim_iw = m.dof_invweight0[c];
-#pragma unroll
-        for (int j = 0; j < 5; j++) lim_si[j] = m.dof_solimp[5 * c + j];
-        if (my_act >= 0) {
-            my_ctrl = s.ctrl[(size_t)my_act * N + e];
-            act_p[0] = m.act_kp[my_act]; act_p[1] = m.act_gear[my_act];
-            act_p[2] = m.act_ctrlrange[2 * my_act]; act_p[3] = m.act_ctrlrange[2 * my_act + 1];
-            act_p[4] = m.act_forcerange[2 * my_act]; act_p[5] = m.act_forcerange[2 * my_act + 1];
-        }
-    }
+    if (isdof) { qvel_c = s.qvel[(size_t)c * N + e]; warm_c = s.warm[(size_t)c * N + e]; }
     const v3 goal = mk3(s.mocap[e], s.mocap[N + e], s.mocap[2 * N + e]);
     float time_e = s.time[e];
     int nsteps_e = 0;
@@ -94,11 +76,23 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(DevModel m, DevState s, i
         // ---------------- K: kinematics of this env by lane 0 of its group, on LDS views
         qposL[c] = qpos_c; qvelL[c] = qvel_c;
         __syncthreads();
-        if (valid && c == 0) {
-            kin_env(m, View{qposL, 1}, View{qvelL, 1}, View{xposL, 1}, View{xmatL, 1}, View{kAng, 1}, View{kLin, 1}, View{kAnc, 1}, View{lk, 1},
-                    View{recL, 1}, View{recL + 3 * m.nlink, 1}, View{recL + 6 * m.nlink, 1}, View{recL + 9 * m.nlink, 1});
+        {
+            // lane = link, one tree level at a time (parents first); the per-link code is shared with k_kinematics
+            const View vq{qposL, 1}, vv{qvelL, 1}, vx{xposL, 1}, vm{xmatL, 1}, va{kAng, 1}, vl{kLin, 1}, vn{kAnc, 1}, vd{lk, 1};
+            const View w0{recL, 1}, w1{recL + 3 * m.nlink, 1}, w2{recL + 6 * m.nlink, 1}, w3{recL + 9 * m.nlink, 1};
+            const int mydepth = (c < m.nlink && c < NLMAX) ? sDepth[c] : -1;
+            if (valid && c == 0) kin_link0(vx, vm, vd, w0, w1, w2, w3);
+            __syncthreads();
+            for (int dlev = 1; dlev <= m.maxdepth; dlev++) {
+                if (valid && mydepth == dlev) kin_link_pose(m, c, vq, vx, vm, va, vl, vn);
+                __syncthreads();
+            }
+            for (int dlev = 1; dlev <= m.maxdepth; dlev++) {
+                if (valid && mydepth == dlev) kin_link_dyn(m, c, vv, vx, vm, va, vl, vn, vd, w0, w1, w2, w3);
+                __syncthreads();
+            }
         }
-        __syncthreads();
+        PHASE(16);
         qpos_c = qposL[c];                                   // mj_kinematics normalises free-joint quaternions in place
         if (!(fabsf(qpos_c) <= 1e10f) || !(fabsf(qvel_c) <= 1e10f)) bad = 1;
         // a-3 goal test uses the xpos of this substep's forward pass
@@ -163,11 +157,32 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(DevModel m, DevState s, i
         }
         __threadfence_block();       // contact records written to global by other lanes of this workgroup
         __syncthreads();
+        PHASE(17);
         // ---------------- S: dynamics + constraint solve + Euler (shared body)
         constexpr int MAXCH = 256 / G;
         int cnt_ch[MAXCH];
 #pragma unroll
         for (int ch = 0; ch < MAXCH; ch++) { const int p = ch * G + c; cnt_ch[ch] = (valid && p < m.npair) ? pcnt[p] : 0; }
+        // per-lane model constants are (re)loaded here, L2-resident, so that they are not live across the collision phase
+        float my_ctrl = 0, damp_c = 0;
+        int my_type = -1, my_qadr = 0, my_quat_lane = -1, my_limited = 0, my_act = -1;
+        float lim_lo = 0, lim_hi = 0, lim_sr0 = 1, lim_sr1 = 1, lim_iw = 0, lim_si[5] = {0, 0, 0, 0, 0};
+        float act_p[6] = {0, 0, 0, 0, 0, 0};
+        if (isdof) {
+            my_type = m.dof_type[c]; my_qadr = m.dof_qposadr[c]; my_limited = m.dof_limited[c]; my_act = m.dof_act[c];
+            my_quat_lane = m.link_dofadr[m.dof_link[c]] + 3;
+            damp_c = m.dof_damping[c];
+            lim_lo = m.dof_range[2 * c]; lim_hi = m.dof_range[2 * c + 1]; lim_sr0 = m.dof_solref[2 * c]; lim_sr1 = m.dof_solref[2 * c + 1];
+            lim_iw = m.dof_invweight0[c];
+#pragma unroll
+            for (int j = 0; j < 5; j++) lim_si[j] = m.dof_solimp[5 * c + j];
+            if (my_act >= 0) {
+                my_ctrl = s.ctrl[(size_t)my_act * N + e];
+                act_p[0] = m.act_kp[my_act]; act_p[1] = m.act_gear[my_act];
+                act_p[2] = m.act_ctrlrange[2 * my_act]; act_p[3] = m.act_ctrlrange[2 * my_act + 1];
+                act_p[4] = m.act_forcerange[2 * my_act]; act_p[5] = m.act_forcerange[2 * my_act + 1];
+            }
+        }
         // per-dof view of qpos (scalar joints: their own coordinate; free joints: lin dofs their coordinate)
         float my_q = 0;
         q4 quat0; quat0.w = 1; quat0.x = quat0.y = quat0.z = 0;
@@ -210,6 +225,7 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(DevModel m, DevState s, i
                 if (reach) done = true;          // a-4: latch; the env skips the remaining substeps
             }
             __syncthreads();
+            PHASE(18);
         }
     }
     // ---------------- write the state back (struct-of-arrays)

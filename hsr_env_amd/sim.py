@@ -35,7 +35,7 @@ EXPORTS = [
     "hsr_batch_reset", "hsr_batch_reset_dev", "hsr_batch_get_state", "hsr_batch_set_state", "hsr_batch_set_mocap",
     "hsr_batch_set_warmstart", "hsr_batch_get_warmstart", "hsr_batch_forward", "hsr_batch_step",
     "hsr_batch_step_dev", "hsr_batch_body_xpos", "hsr_batch_bad_state", "hsr_batch_get_field",
-    "hsr_batch_set_profiling", "hsr_batch_last_timing", "hsr_batch_set_graph",
+    "hsr_batch_set_profiling", "hsr_batch_last_timing", "hsr_batch_set_graph", "hsr_batch_set_persistent", "hsr_batch_is_persistent",
 ]
 
 F_XPOS, F_XMAT, F_M, F_QACC, F_QACC_SMOOTH, F_QFRC_SMOOTH, F_QFRC_CONSTRAINT, F_NCON, F_NEFC, F_CONTACT, F_NITER = range(11)
@@ -84,6 +84,8 @@ def load_library():
     L.hsr_batch_set_profiling.argtypes = [vp, C.c_int]
     L.hsr_batch_last_timing.argtypes = [vp, fp, fp, C.POINTER(C.c_int)]
     L.hsr_batch_set_graph.argtypes = [vp, C.c_int]
+    L.hsr_batch_set_persistent.argtypes = [vp, C.c_int]
+    L.hsr_batch_is_persistent.argtypes = [vp]
     _lib = L
     return L
 
@@ -221,6 +223,12 @@ class BatchSim:
 
     def set_graph(self, on: bool):
         _check(self._L, self._L.hsr_batch_set_graph(self._b, int(on)))
+
+    def set_persistent(self, on: bool) -> bool:
+        return bool(self._L.hsr_batch_set_persistent(self._b, int(on)))
+
+    def is_persistent(self) -> bool:
+        return bool(self._L.hsr_batch_is_persistent(self._b))
 
     def last_timing(self):
         tot = C.c_float(0); k = (C.c_float * 3)(); n = (C.c_int * 3)()

@@ -99,8 +99,12 @@ int hsr_batch_get_field(hsr_batch *b, int field, float *out);
  * enable with hsr_batch_set_profiling(b, 1).  kernel order: kinematics, collide, solve */
 int hsr_batch_set_profiling(hsr_batch *b, int on);
 int hsr_batch_last_timing(hsr_batch *b, float *total_ms, float *kernel_ms /*[3]*/, int *launches /*[3]*/);
-/* use a captured hipGraph for the substep loop (default on) */
+/* use a captured hipGraph for the substep loop of the per-substep-kernel path (default on) */
 int hsr_batch_set_graph(hsr_batch *b, int on);
+/* whole env-step in ONE persistent kernel (default on when the model fits: nv <= 32, LDS budget); returns the
+ * resulting setting.  With it on, hsr_batch_last_timing() reports the persistent kernel in slot 2 (slots 0,1 = 0). */
+int hsr_batch_set_persistent(hsr_batch *b, int on);
+int hsr_batch_is_persistent(const hsr_batch *b);
 
 #ifdef __cplusplus
 }

@@ -20,9 +20,9 @@ L.hsr_batch_phase_cycles(sim._b, buf)
 ctrl = rng.uniform(m.act_ctrlrange[:, 0], m.act_ctrlrange[:, 1], (n, m.nu)).astype(np.float32)
 sim.step(ctrl, 300, m.body_id('block0'), 0.05)
 L.hsr_batch_phase_cycles(sim._b, buf)
-v = np.array(list(buf), dtype=np.float64)[:18]
+v = np.array(list(buf), dtype=np.float64)[:19]
 names = ['A load', 'B/C M+bias', 'D chol M+solve', 'E1-2 limits+compact', 'E3 contact rec', 'E4-5 J rows', 'F0 warm evals', 'F grad',
-         'F hess', 'F chol+solve', 'F ls setup+ls', 'F update+eval', 'qfc..stores+G chol(12)', 'G solve..stores+tail(13)', 'loop exit+qfc jt_force(14)', 'G chol only(15)', 'vnew+shfl(16)', 'stores qvel/warm/qpos(17)']
+         'F hess', 'F chol+solve', 'F ls setup+ls', 'F update+eval', 'qfc..stores+G chol(12)', 'G solve..stores+tail(13)', 'loop exit+qfc jt_force(14)', 'G chol only(15)', 'K kinematics(16)', 'C collision(17)', 'integrate+regs(18)']
 tot = v.sum()
 for nm, x in zip(names, v):
     print(f'{nm:22s} {x / tot * 100:6.2f} %   {x / (2048 * 300):9.0f} cyc/block/substep')
@@ -31,4 +31,4 @@ print('total cyc/block/substep', tot / (2048 * 300))
 w = np.array(list(buf), dtype=np.float64)
 print('MPR: calls/substep %.1f  cache hits/substep %.1f  supports/call %.2f  max supports in a call %d  calls with >20 supports per substep %.2f' % (
     w[22] / 300, w[23] / 300, w[20] / max(w[22], 1), w[21], w[24] / 300))
-print('in-kernel clock: %.2f GHz (s_memtime / s_memrealtime * 100 MHz); mean block lifetime %.1f us' % (w[26] / max(w[27], 1) * 0.1, w[27] / (2048 * 300) / 100.0))
+print('in-kernel clock: %.2f GHz (s_memtime / s_memrealtime * 100 MHz); mean block lifetime per substep %.1f us' % (w[26] / max(w[27], 1) * 0.1, w[27] / (2048 * 300) / 100.0))
