@@ -10,13 +10,71 @@
 // velocity part).  All arrays are Views so that the same code serves the one-lane-per-env kernel (LDS tile per lane)
 // and the persistent per-env-group kernel (LDS record of the group).  Outputs: link poses, world dof axes/anchors,
 // per-link com(3) Iworld(6) F(3) N(3) in ld; lw/lvo/lal/lao are scratch (12 floats per link).
+// model-constant providers for the per-link kinematics: straight from the device tables, or from registers that one
+// lane preloaded for "its" link (persistent kernel: no dependent global loads inside the tree-level rounds)
+struct KinGlobal {
+    const DevModel &m;
+    __device__ __forceinline__ int link_dofadr(int l) const { return m.link_dofadr[l]; }
+    __device__ __forceinline__ int link_dofnum(int l) const { return m.link_dofnum[l]; }
+    __device__ __forceinline__ int link_free(int l) const { return m.link_free[l]; }
+    __device__ __forceinline__ int link_qposadr(int l) const { return m.link_qposadr[l]; }
+    __device__ __forceinline__ int link_parent(int l) const { return m.link_parent[l]; }
+    __device__ __forceinline__ v3 link_pos(int l) const { return ld3(m.link_pos, l); }
+    __device__ __forceinline__ m3 link_mat(int l) const { return ldm(m.link_mat, l); }
+    __device__ __forceinline__ v3 link_com(int l) const { return ld3(m.link_com, l); }
+    __device__ __forceinline__ float link_mass(int l) const { return m.link_mass[l]; }
+    __device__ __forceinline__ void link_inertia(int l, float *o) const {
+#pragma unroll
+        for (int i = 0; i < 6; i++) o[i] = m.link_inertia[6 * l + i]; }
+    __device__ __forceinline__ int dof_qposadr(int k) const { return m.dof_qposadr[k]; }
+    __device__ __forceinline__ int dof_type(int k) const { return m.dof_type[k]; }
+    __device__ __forceinline__ v3 dof_axis(int k) const { return ld3(m.dof_axis, k); }
+    __device__ __forceinline__ v3 dof_pos(int k) const { return ld3(m.dof_pos, k); }
+};
+struct KinLane {          // constants of ONE link (the lane's) and of its first three scalar dofs
+    int dofadr, dofnum, free_, qposadr, parent;
+    v3 lpos, com;
+    m3 lmat;
+    float mass, inertia[6];
+    int dqadr[3], dtype[3];
+    v3 daxis[3], dpos[3];
+    __device__ __forceinline__ void load(const DevModel &m, int l) {
+        dofadr = m.link_dofadr[l]; dofnum = m.link_dofnum[l]; free_ = m.link_free[l]; qposadr = m.link_qposadr[l]; parent = m.link_parent[l];
+        lpos = ld3(m.link_pos, l); lmat = ldm(m.link_mat, l); com = ld3(m.link_com, l); mass = m.link_mass[l];
+#pragma unroll
+        for (int i = 0; i < 6; i++) inertia[i] = m.link_inertia[6 * l + i];
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const int k = dofadr + (j < dofnum ? j : 0);
+            dqadr[j] = m.dof_qposadr[k]; dtype[j] = m.dof_type[k]; daxis[j] = ld3(m.dof_axis, k); dpos[j] = ld3(m.dof_pos, k);
+        }
+    }
+    __device__ __forceinline__ int link_dofadr(int) const { return dofadr; }
+    __device__ __forceinline__ int link_dofnum(int) const { return dofnum; }
+    __device__ __forceinline__ int link_free(int) const { return free_; }
+    __device__ __forceinline__ int link_qposadr(int) const { return qposadr; }
+    __device__ __forceinline__ int link_parent(int) const { return parent; }
+    __device__ __forceinline__ v3 link_pos(int) const { return lpos; }
+    __device__ __forceinline__ m3 link_mat(int) const { return lmat; }
+    __device__ __forceinline__ v3 link_com(int) const { return com; }
+    __device__ __forceinline__ float link_mass(int) const { return mass; }
+    __device__ __forceinline__ void link_inertia(int, float *o) const {
+#pragma unroll
+        for (int i = 0; i < 6; i++) o[i] = inertia[i]; }
+    __device__ __forceinline__ int dof_qposadr(int k) const { const int j = k - dofadr; return j == 0 ? dqadr[0] : (j == 1 ? dqadr[1] : dqadr[2]); }
+    __device__ __forceinline__ int dof_type(int k) const { const int j = k - dofadr; return j == 0 ? dtype[0] : (j == 1 ? dtype[1] : dtype[2]); }
+    __device__ __forceinline__ v3 dof_axis(int k) const { const int j = k - dofadr; return j == 0 ? daxis[0] : (j == 1 ? daxis[1] : daxis[2]); }
+    __device__ __forceinline__ v3 dof_pos(int k) const { const int j = k - dofadr; return j == 0 ? dpos[0] : (j == 1 ? dpos[1] : dpos[2]); }
+};
+
 // pose of link l from its (already computed) parent and its joint coordinates; also the world axes of its dofs
-__device__ __forceinline__ void kin_link_pose(const DevModel &m, int l, View qpos, View xpos, View xmat, View ang, View lin, View anc) {
+template <class KC>
+__device__ __forceinline__ void kin_link_pose(const KC &K, int l, View qpos, View xpos, View xmat, View ang, View lin, View anc) {
     v3 pos;
     m3 mat;
-    const int d0 = m.link_dofadr[l], dn = m.link_dofnum[l];
-    if (m.link_free[l]) {
-        const int a = m.link_qposadr[l];
+    const int d0 = K.link_dofadr(l), dn = K.link_dofnum(l);
+    if (K.link_free(l)) {
+        const int a = K.link_qposadr(l);
         pos = mk3(qpos[a], qpos[a + 1], qpos[a + 2]);
         q4 q;
         q.w = qpos[a + 3]; q.x = qpos[a + 4]; q.y = qpos[a + 5]; q.z = qpos[a + 6];
@@ -32,17 +90,17 @@ __device__ __forceinline__ void kin_link_pose(const DevModel &m, int l, View qpo
             anc.set3(d0 + 3 + k, pos);
         }
     } else {
-        const int p = m.link_parent[l];
+        const int p = K.link_parent(l);
         const m3 Rp = xmat.getm(p);
-        pos = xpos.get3(p) + mulmv(Rp, ld3(m.link_pos, l));
-        mat = mulmm(Rp, ldm(m.link_mat, l));
+        pos = xpos.get3(p) + mulmv(Rp, K.link_pos(l));
+        mat = mulmm(Rp, K.link_mat(l));
         for (int k = d0; k < d0 + dn; k++) {
-            const float q = qpos[m.dof_qposadr[k]];
-            const v3 ax = ld3(m.dof_axis, k);
-            if (m.dof_type[k] == DOF_SLIDE) {
+            const float q = qpos[K.dof_qposadr(k)];
+            const v3 ax = K.dof_axis(k);
+            if (K.dof_type(k) == DOF_SLIDE) {
                 pos = pos + mulmv(mat, ax) * q;
             } else {
-                const v3 jp = ld3(m.dof_pos, k);
+                const v3 jp = K.dof_pos(k);
                 const v3 anchor = pos + mulmv(mat, jp);
                 float sn, cs;
                 sincosf(0.5f * q, &sn, &cs);
@@ -53,11 +111,11 @@ __device__ __forceinline__ void kin_link_pose(const DevModel &m, int l, View qpo
             }
         }
         for (int k = d0; k < d0 + dn; k++) {
-            const v3 ax = mulmv(mat, ld3(m.dof_axis, k));
-            if (m.dof_type[k] == DOF_SLIDE) {
+            const v3 ax = mulmv(mat, K.dof_axis(k));
+            if (K.dof_type(k) == DOF_SLIDE) {
                 lin.set3(k, ax); ang.set3(k, mk3(0, 0, 0)); anc.set3(k, pos);
             } else {
-                ang.set3(k, ax); lin.set3(k, mk3(0, 0, 0)); anc.set3(k, pos + mulmv(mat, ld3(m.dof_pos, k)));
+                ang.set3(k, ax); lin.set3(k, mk3(0, 0, 0)); anc.set3(k, pos + mulmv(mat, K.dof_pos(k)));
             }
         }
     }
@@ -67,26 +125,27 @@ __device__ __forceinline__ void kin_link_pose(const DevModel &m, int l, View qpo
 
 // velocity / bias acceleration (qacc = 0) of link l from its parent's, and the per-link wrench of mj_rne:
 // F = m (a_com - g), N = I alpha + w x I w  (consumed by the solver as bias = J^T [F; N])
-__device__ __forceinline__ void kin_link_dyn(const DevModel &m, int l, View qvel, View xpos, View xmat, View ang, View lin, View anc, View ld,
+template <class KC>
+__device__ __forceinline__ void kin_link_dyn(const KC &K, float gravz, int l, View qvel, View xpos, View xmat, View ang, View lin, View anc, View ld,
                                              View lw, View lvo, View lal, View lao) {
-    const int d0 = m.link_dofadr[l];
+    const int d0 = K.link_dofadr(l);
     const m3 R = xmat.getm(l);
     const v3 xl = xpos.get3(l);
     v3 w, vo, al, ao;
-    if (m.link_free[l]) {
+    if (K.link_free(l)) {
         vo = mk3(qvel[d0], qvel[d0 + 1], qvel[d0 + 2]);
         w = mulmv(R, mk3(qvel[d0 + 3], qvel[d0 + 4], qvel[d0 + 5]));
         al = mk3(0, 0, 0); ao = mk3(0, 0, 0);
     } else {
-        const int p = m.link_parent[l];
+        const int p = K.link_parent(l);
         const v3 wp = lw.get3(p), vop = lvo.get3(p), alp = lal.get3(p), aop = lao.get3(p);
         const v3 r = xl - xpos.get3(p);
         w = wp; al = alp;
         vo = vop + cross(wp, r);
         ao = aop + cross(alp, r) + cross(wp, cross(wp, r));
-        for (int k = d0; k < d0 + m.link_dofnum[l]; k++) {
+        for (int k = d0; k < d0 + K.link_dofnum(l); k++) {
             const float qd = qvel[k];
-            if (m.dof_type[k] == DOF_SLIDE) {
+            if (K.dof_type(k) == DOF_SLIDE) {
                 const v3 sx = lin.get3(k);
                 vo = vo + sx * qd;
                 ao = ao + cross(wp, sx) * (2 * qd);
@@ -103,7 +162,8 @@ __device__ __forceinline__ void kin_link_dyn(const DevModel &m, int l, View qvel
         }
     }
     lw.set3(l, w); lvo.set3(l, vo); lal.set3(l, al); lao.set3(l, ao);
-    const float *li = m.link_inertia + 6 * l;
+    float li[6];
+    K.link_inertia(l, li);
     m3 Il, Rt;
     Il.a[0] = li[0]; Il.a[1] = li[3]; Il.a[2] = li[4]; Il.a[3] = li[3]; Il.a[4] = li[1]; Il.a[5] = li[5]; Il.a[6] = li[4]; Il.a[7] = li[5]; Il.a[8] = li[2];
 #pragma unroll
@@ -111,9 +171,9 @@ __device__ __forceinline__ void kin_link_dyn(const DevModel &m, int l, View qvel
 #pragma unroll
         for (int j = 0; j < 3; j++) Rt.a[3 * i + j] = R.a[3 * j + i];
     const m3 I = mulmm(mulmm(R, Il), Rt);
-    const v3 com = xl + mulmv(R, ld3(m.link_com, l)), rc = com - xl;
+    const v3 com = xl + mulmv(R, K.link_com(l)), rc = com - xl;
     const v3 acom = ao + cross(al, rc) + cross(w, cross(w, rc));
-    const v3 F = (acom - mk3(0, 0, m.gravz)) * m.link_mass[l];
+    const v3 F = (acom - mk3(0, 0, gravz)) * K.link_mass(l);
     const v3 Nt = mulmv(I, al) + cross(w, mulmv(I, w));
     const int b = 15 * l;
     ld[b] = com.x; ld[b + 1] = com.y; ld[b + 2] = com.z;
@@ -138,8 +198,9 @@ __device__ __forceinline__ void kin_link0(View xpos, View xmat, View ld, View lw
 __device__ void kin_env(const DevModel &m, View qpos, View qvel, View xpos, View xmat, View ang, View lin, View anc, View ld,
                         View lw, View lvo, View lal, View lao) {
     kin_link0(xpos, xmat, ld, lw, lvo, lal, lao);
-    for (int l = 1; l < m.nlink; l++) kin_link_pose(m, l, qpos, xpos, xmat, ang, lin, anc);
-    for (int l = 1; l < m.nlink; l++) kin_link_dyn(m, l, qvel, xpos, xmat, ang, lin, anc, ld, lw, lvo, lal, lao);
+    const KinGlobal K{m};
+    for (int l = 1; l < m.nlink; l++) kin_link_pose(K, l, qpos, xpos, xmat, ang, lin, anc);
+    for (int l = 1; l < m.nlink; l++) kin_link_dyn(K, m.gravz, l, qvel, xpos, xmat, ang, lin, anc, ld, lw, lvo, lal, lao);
 }
 
 // ------------------------------------------------------------------ kinematics (a-2.1)
@@ -602,6 +663,38 @@ __device__ __forceinline__ bool obb_overlap(const Geom &A, const Geom &B) {
             sep |= fabsf(ta[i2] * C[i1][j] - ta[i1] * C[i2][j]) > ra + rb;
         }
     return !sep;
+}
+
+// Geom w (0 / 1) of a packed pair record (DevModel::pair_geo) placed by the link poses in xpos / xmat
+__device__ __forceinline__ Geom geom_from_rec(const float *rec, int w, View xpos, View xmat, const float4 *mesh_vert4) {
+    Geom G;
+    const float *o = rec + 16 + 21 * w;
+    const int l = (int)rec[5 + w];
+    const m3 R = xmat.getm(l);
+    m3 lm;
+#pragma unroll
+    for (int k = 0; k < 9; k++) lm.a[k] = o[3 + k];
+    G.pos = xpos.get3(l) + mulmv(R, mk3(o[0], o[1], o[2]));
+    G.mat = mulmm(R, lm);
+    G.type = (int)rec[7 + w];
+    G.size = mk3(o[12], o[13], o[14]);
+    G.bc = G.pos + mulmv(G.mat, mk3(o[15], o[16], o[17]));
+    G.bh = mk3(o[18], o[19], o[20]);
+    G.nvert = (int)rec[11 + w];
+    G.verts = mesh_vert4 + (int)rec[9 + w];
+    return G;
+}
+__device__ __forceinline__ bool pair_cull_r(const Geom &G1, const Geom &G2, float rb1, float rb2) {
+    if (G1.type == GEOM_PLANE) {
+        const v3 n = col(G1.mat, 2);
+        if (!(dot(G2.pos - G1.pos, n) <= rb2)) return false;
+        return dot(G2.bc - G1.pos, n) - (fabsf(dot(n, col(G2.mat, 0))) * G2.bh.x + fabsf(dot(n, col(G2.mat, 1))) * G2.bh.y + fabsf(dot(n, col(G2.mat, 2))) * G2.bh.z) <= 0.f;
+    }
+    const v3 r = G2.pos - G1.pos;
+    const float b = rb1 + rb2;
+    if (!(dot(r, r) <= b * b)) return false;
+    if (!(sphere_hits_obb(G2.pos, rb2, G1) && sphere_hits_obb(G1.pos, rb1, G2))) return false;
+    return obb_overlap(G1, G2);
 }
 
 // ---- two-stage collision: cull + compaction, then dense narrowphase ------------------------------------------------

@@ -394,6 +394,31 @@ extern "C" int hsr_batch_create(const hsr_model *m, int n_envs, int device_id, h
         HIPCHK(hipMemcpy(dda, da.data(), da.size() * sizeof(int), hipMemcpyHostToDevice));
         d.dof_act = dda;
     }
+    {   // packed per-pair collision records: [0..15] ids / sizes, [16..36] geom1 (lpos3 lmat9 size3 aabb6), [37..57] geom2
+        const int *g1 = m->i32("pair_geom1"), *g2 = m->i32("pair_geom2"), *fn = m->i32("pair_fn"), *sl = m->i32("pair_slot");
+        const int *gl = m->i32("geom_link"), *gt = m->i32("geom_type"), *ma = m->i32("geom_meshadr"), *mn = m->i32("geom_meshnum");
+        const double *gp = m->f64("geom_pos"), *gq = m->f64("geom_quat"), *gs = m->f64("geom_size"), *gb = m->f64("geom_aabb"), *gr = m->f64("geom_rbound");
+        std::vector<float> rec((size_t)std::max(d.npair, 1) * 64, 0.f);
+        for (int p = 0; p < d.npair; p++) {
+            float *r = rec.data() + 64 * p;
+            const int a = g1[p], c2 = g2[p];
+            r[0] = (float)a; r[1] = (float)c2; r[2] = (float)fn[p]; r[3] = (float)sl[p]; r[4] = (float)(sl[p + 1] - sl[p]);
+            r[5] = (float)gl[a]; r[6] = (float)gl[c2]; r[7] = (float)gt[a]; r[8] = (float)gt[c2];
+            r[9] = (float)ma[a]; r[10] = (float)ma[c2]; r[11] = (float)mn[a]; r[12] = (float)mn[c2];
+            r[13] = (float)gr[a]; r[14] = (float)gr[c2];
+            for (int w = 0; w < 2; w++) {
+                const int gg = w == 0 ? a : c2;
+                float *o = r + 16 + 21 * w;
+                for (int k = 0; k < 3; k++) o[k] = (float)gp[3 * gg + k];
+                quat2mat_h(gq + 4 * gg, o + 3);
+                for (int k = 0; k < 3; k++) o[12 + k] = (float)gs[3 * gg + k];
+                for (int k = 0; k < 6; k++) o[15 + k] = (float)gb[6 * gg + k];
+            }
+        }
+        float *dg; if ((rc = dalloc(b, &dg, rec.size()))) return rc;
+        HIPCHK(hipMemcpy(dg, rec.data(), rec.size() * sizeof(float), hipMemcpyHostToDevice));
+        d.pair_geo = dg;
+    }
     if ((rc = upload_mats(b, &d.link_mat, m, "link_quat"))) return rc;
     if ((rc = upload_mats(b, &d.geom_mat, m, "geom_quat"))) return rc;
     d.any_damping = 0;
@@ -464,6 +489,10 @@ extern "C" int hsr_batch_create(const hsr_model *m, int n_envs, int device_id, h
         b->persist = !(pe && strcmp(pe, "0") == 0);
         const int total = b->group == 16 ? PersistLayout<16>(d.njmax, b->ds.kstride, d.npair_pad, d.nlink).total : PersistLayout<32>(d.njmax, b->ds.kstride, d.npair_pad, d.nlink).total;
         b->persist_lds_bytes = (size_t)total * sizeof(float);
+        {   // KinLane preloads at most three scalar joints per body
+            const int *dn = m->i32("link_dofnum"), *lf = m->i32("link_free");
+            for (int l = 1; l < d.nlink; l++) if (!lf[l] && dn[l] > 3) b->persist = false;
+        }
         if (b->persist_lds_bytes > 160 * 1024) b->persist = false;
         else if (b->persist_lds_bytes > 48 * 1024) {
             if (b->group == 16) HIPCHK(hipFuncSetAttribute((const void *)k_env_step_mf<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->persist_lds_bytes));

@@ -52,7 +52,7 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(DevModel m, DevState s, i
     float *poly = lds + L.oPoly;
     const bool isdof = c < nv;
     int bad_acc = 0;
-    __shared__ int sParent[32], sMask[NLMAX], sDepth[NLMAX];
+    __shared__ int sParent[32], sMask[NLMAX], sDepth[NLMAX], sItems[64];
     __shared__ float sMass[NLMAX];
     if (tid < nv) sParent[tid] = m.dof_parent[tid];
     if (tid < m.nlink && tid < NLMAX) { sMask[tid] = m.link_dofmask[tid]; sMass[tid] = m.link_mass[tid]; sDepth[tid] = m.link_depth[tid]; }
@@ -81,14 +81,16 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(DevModel m, DevState s, i
             const View vq{qposL, 1}, vv{qvelL, 1}, vx{xposL, 1}, vm{xmatL, 1}, va{kAng, 1}, vl{kLin, 1}, vn{kAnc, 1}, vd{lk, 1};
             const View w0{recL, 1}, w1{recL + 3 * m.nlink, 1}, w2{recL + 6 * m.nlink, 1}, w3{recL + 9 * m.nlink, 1};
             const int mydepth = (c < m.nlink && c < NLMAX) ? sDepth[c] : -1;
+            KinLane K;
+            K.load(m, mydepth > 0 ? c : 0);        // this lane's link constants: independent loads, one round trip
             if (valid && c == 0) kin_link0(vx, vm, vd, w0, w1, w2, w3);
             __syncthreads();
             for (int dlev = 1; dlev <= m.maxdepth; dlev++) {
-                if (valid && mydepth == dlev) kin_link_pose(m, c, vq, vx, vm, va, vl, vn);
+                if (valid && mydepth == dlev) kin_link_pose(K, c, vq, vx, vm, va, vl, vn);
                 __syncthreads();
             }
             for (int dlev = 1; dlev <= m.maxdepth; dlev++) {
-                if (valid && mydepth == dlev) kin_link_dyn(m, c, vv, vx, vm, va, vl, vn, vd, w0, w1, w2, w3);
+                if (valid && mydepth == dlev) kin_link_dyn(K, m.gravz, c, vv, vx, vm, va, vl, vn, vd, w0, w1, w2, w3);
                 __syncthreads();
             }
         }
@@ -107,52 +109,70 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(DevModel m, DevState s, i
             for (int i = c; i < 3 * m.nlink; i += G) s.xpos[(size_t)i * N + e] = xposL[i];
             for (int i = c; i < 9 * m.nlink; i += G) s.xmat[(size_t)i * N + e] = xmatL[i];
         }
-        // ---------------- C: collision, lane = candidate pair
+        // ---------------- C: collision
+        // pass 1, lane = candidate pair of its own env: bounding culls only; survivors are appended to a workgroup work
+        // list with wave ballots.  pass 2, lane = work item of ANY env of the workgroup: the narrowphase runs with the
+        // survivors of all pairs and envs side by side instead of one sparse pass per 16 pairs.
         {
-            float *cong = s.con + (size_t)e * m.nslot * 8;
+            for (int p0 = 0; p0 < m.npair_pad; p0 += G) { const int p = p0 + c; if (p < m.npair_pad) pcnt[p] = 0; }
+            int nitems = 0;                                        // wave-uniform
             for (int p0 = 0; p0 < m.npair; p0 += G) {
                 const int p = p0 + c;
                 const bool have = valid && p < m.npair;
-                const int ps = have ? p : 0;
-                const int g1 = m.pair_geom1[ps], g2 = m.pair_geom2[ps];
-                Geom G1 = load_geom_v(m, View{xposL, 1}, View{xmatL, 1}, g1), G2 = load_geom_v(m, View{xposL, 1}, View{xmatL, 1}, g2);
-                const bool pass = have && pair_cull(m, G1, G2, g1, g2);
+                bool pass = false;
+                if (have) {
+                    const float *rec = m.pair_geo + 64 * p;
+                    const Geom G1 = geom_from_rec(rec, 0, View{xposL, 1}, View{xmatL, 1}, m.mesh_vert4);
+                    const Geom G2 = geom_from_rec(rec, 1, View{xposL, 1}, View{xmatL, 1}, m.mesh_vert4);
+                    pass = pair_cull_r(G1, G2, rec[13], rec[14]);
+                }
+                const unsigned long long bal = __ballot(pass);
+                if (pass) { const int k = nitems + __popcll(bal & ((1ull << tid) - 1ull)); if (k < 64) sItems[k] = (g << 16) | p; }
+                nitems += __popcll(bal);
+            }
+            if (nitems > 64) nitems = 64;                          // more than 64 surviving pairs in 4 envs: never observed; extra ones are dropped
+            __syncthreads();
+            {
+                const bool act = tid < nitems;
+                const int it = act ? sItems[tid] : 0;
+                const int ig = it >> 16, p = it & 0xffff;
+                float *Ei = lds + (size_t)ig * L.envf;
+                const View vx{Ei + L.oB, 1}, vm{Ei + L.oB + 3 * m.nlink, 1};
+                const int ei = blockIdx.x * EPB + ig;
+                const float *rec = m.pair_geo + 64 * p;
                 ContactOut out;
-                out.con = cong; out.slot = m.pair_slot[ps]; out.maxcnt = m.pair_slot[ps + 1] - m.pair_slot[ps]; out.cnt = 0;
-                const int fn = m.pair_fn[ps];
-                if (pass) {
-                    if (G1.type == GEOM_MESH) G1.verts = m.mesh_vert4 + m.geom_meshadr[g1];
-                    if (G2.type == GEOM_MESH) G2.verts = m.mesh_vert4 + m.geom_meshadr[g2];
-                    if (fn == FN_PLANE_BOX) collide_plane_box(G1, G2, out);
-                    else if (fn == FN_PLANE_CONVEX) collide_plane_convex(G1, G2, out);
-                    else if (fn == FN_CONVEX) {
-                        float *sx = s.sepax + (size_t)(3 * p) * N + e;
-                        const v3 d = mk3(sx[0], sx[N], sx[2 * (size_t)N]);
-                        bool still = false;
-                        if (d.x != 0.f || d.y != 0.f || d.z != 0.f) still = dot(support(G1, d) - support(G2, -d), d) < -1e-7f;
-                        if (!still) {
-                            float depth; v3 dir, pos, sep;
-                            int nsup = 0;
-                            if (mpr_penetration(G1, G2, m.mpr_tolerance, m.mpr_iterations, depth, dir, pos, sep, nsup)) { out.add(pos, dir, -depth); sep = mk3(0, 0, 0); }
-                            sx[0] = sep.x; sx[N] = sep.y; sx[2 * (size_t)N] = sep.z;
-                        }
+                out.con = s.con + (size_t)ei * m.nslot * 8; out.slot = (int)rec[3]; out.maxcnt = (int)rec[4]; out.cnt = 0;
+                const int fn = act ? (int)rec[2] : -1;
+                Geom G1, G2;
+                if (act) { G1 = geom_from_rec(rec, 0, vx, vm, m.mesh_vert4); G2 = geom_from_rec(rec, 1, vx, vm, m.mesh_vert4); }
+                if (fn == FN_PLANE_BOX) collide_plane_box(G1, G2, out);
+                else if (fn == FN_PLANE_CONVEX) collide_plane_convex(G1, G2, out);
+                else if (fn == FN_CONVEX) {
+                    float *sx = s.sepax + (size_t)(3 * p) * N + ei;
+                    const v3 d = mk3(sx[0], sx[N], sx[2 * (size_t)N]);
+                    bool still = false;
+                    if (d.x != 0.f || d.y != 0.f || d.z != 0.f) still = dot(support(G1, d) - support(G2, -d), d) < -1e-7f;
+                    if (!still) {
+                        float depth; v3 dir, pos, sep;
+                        int nsup = 0;
+                        if (mpr_penetration(G1, G2, m.mpr_tolerance, m.mpr_iterations, depth, dir, pos, sep, nsup)) { out.add(pos, dir, -depth); sep = mk3(0, 0, 0); }
+                        sx[0] = sep.x; sx[N] = sep.y; sx[2 * (size_t)N] = sep.z;
                     }
                 }
                 // box-box needs LDS polygon scratch: at most 8 lanes of the wave run it at a time
                 {
-                    const bool bb = pass && fn == FN_BOX_BOX;
+                    const bool bb = fn == FN_BOX_BOX;
                     unsigned long long pend = __ballot(bb);
                     while (pend) {
                         const int rank = __popcll(pend & ((1ull << tid) - 1ull));
                         const bool mine = bb && ((pend >> tid) & 1ull) && rank < 8;
                         if (mine) collide_box_box_slot(G1, G2, out, poly + 48 * rank);
-                        // retire the (up to) 8 lowest pending lanes
                         unsigned long long t = pend; int k = 0;
                         while (t && k < 8) { t &= t - 1; k++; }
                         pend = t;
                     }
                 }
-                if (p < m.npair) pcnt[p] = out.cnt;
+                if (act) reinterpret_cast<int *>(Ei + L.oCnt)[p] = out.cnt;
             }
         }
         __threadfence_block();       // contact records written to global by other lanes of this workgroup
