@@ -273,7 +273,14 @@ __device__ __forceinline__ Geom load_geom_v(const DevModel &m, View xpos, View x
 }
 
 // support point of a convex geom in world direction dir (ties resolved as in the oracle)
-__device__ __forceinline__ v3 support(const Geom &G, v3 dir) {
+// W > 1: the W consecutive lanes of a sub-group hold the SAME geom and direction and split the hull scan between them
+// (lane i takes vertices i, i + W, ...); a DPP butterfly picks the maximum, lowest index on ties - the same vertex the
+// sequential scan returns.
+template <int W> __device__ __forceinline__ void sup_merge(float &b, int &idx, float pb, int pi) {
+    const bool take = pb > b || (pb == b && pi < idx);
+    b = take ? pb : b; idx = take ? pi : idx;
+}
+template <int W = 1> __device__ __forceinline__ v3 support(const Geom &G, v3 dir) {
     const v3 dl = mulmtv(G.mat, dir);
     v3 loc;
     if (G.type == GEOM_BOX) {
@@ -288,6 +295,28 @@ __device__ __forceinline__ v3 support(const Geom &G, v3 dir) {
         // mesh hull: exhaustive search, first maximum wins (same tie-break as a sequential scan).  Two independent
         // (value, index) chains over even/odd vertices give the VALU two dependency chains; the winning vertex is
         // fetched once at the end.  Vertices are LDS broadcast reads.
+      if constexpr (W > 1) {
+        const int sub = threadIdx.x & (W - 1);
+        float b = -3.0e38f;
+        int idx = 0x7fffffff;
+        for (int i0 = 0; i0 < G.nvert; i0 += 4 * W) {
+            float4 q[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) { const int i = i0 + u * W + sub; q[u] = G.verts[i < G.nvert ? i : 0]; }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int i = i0 + u * W + sub;
+                const float t = q[u].x * dl.x + q[u].y * dl.y + q[u].z * dl.z;
+                if (i < G.nvert && t > b) { b = t; idx = i; }
+            }
+        }
+        sup_merge<W>(b, idx, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, b), 0xB1, 0xf, 0xf, false)), __builtin_amdgcn_update_dpp(0, idx, 0xB1, 0xf, 0xf, false));
+        if constexpr (W >= 4) sup_merge<W>(b, idx, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, b), 0x4E, 0xf, 0xf, false)), __builtin_amdgcn_update_dpp(0, idx, 0x4E, 0xf, 0xf, false));
+        if constexpr (W >= 8) sup_merge<W>(b, idx, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, b), 0x141, 0xf, 0xf, false)), __builtin_amdgcn_update_dpp(0, idx, 0x141, 0xf, 0xf, false));
+        if constexpr (W >= 16) sup_merge<W>(b, idx, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, b), 0x140, 0xf, 0xf, false)), __builtin_amdgcn_update_dpp(0, idx, 0x140, 0xf, 0xf, false));
+        const float4 w = G.verts[G.nvert > 0 ? idx : 0];
+        loc = mk3(w.x, w.y, w.z);
+      } else {
         float bA = -3.0e38f, bB = -3.0e38f;
         int iA = 0, iB = 1;
         int i = 0;
@@ -311,6 +340,7 @@ __device__ __forceinline__ v3 support(const Geom &G, v3 dir) {
         const int best = (bB > bA || (bB == bA && iB < iA)) ? iB : iA;
         const float4 w = G.verts[G.nvert > 0 ? best : 0];
         loc = mk3(w.x, w.y, w.z);
+      }
     }
     return mulmv(G.mat, loc) + G.pos;
 }
@@ -488,10 +518,10 @@ __device__ int g_dbg_nsup_lane;   // unused placeholder to keep the symbol table
 #else
 #define DBG_COUNT_SUPPORT(ctr) do {} while (0)
 #endif
-__device__ __forceinline__ Sup mpr_support(const Geom &G1, const Geom &G2, v3 dir) {
+template <int W = 1> __device__ __forceinline__ Sup mpr_support(const Geom &G1, const Geom &G2, v3 dir) {
     Sup s;
-    s.v1 = support(G1, dir);
-    s.v2 = support(G2, -dir);
+    s.v1 = support<W>(G1, dir);
+    s.v2 = support<W>(G2, -dir);
     s.v = s.v1 - s.v2;
     return s;
 }
@@ -552,7 +582,7 @@ __device__ __forceinline__ bool reach_tol(const Sup &p1, const Sup &p2, const Su
 
 // returns true on penetration; otherwise `sep` is a proven separating direction of the Minkowski difference
 // (support(A-B, sep) . sep < 0) or zero when MPR gave up without one
-__device__ bool mpr_penetration(const Geom &G1, const Geom &G2, float tol, int maxit, float &depth, v3 &dirout, v3 &pos, v3 &sep, int &nsup) {
+template <int W = 1> __device__ bool mpr_penetration(const Geom &G1, const Geom &G2, float tol, int maxit, float &depth, v3 &dirout, v3 &pos, v3 &sep, int &nsup) {
     const float eps = HSR_EPS;
     Sup p0, p1, p2, p3, v4;
     p0.v1 = G1.pos; p0.v2 = G2.pos; p0.v = p0.v1 - p0.v2;
@@ -560,7 +590,7 @@ __device__ bool mpr_penetration(const Geom &G1, const Geom &G2, float tol, int m
     v3 dir = normalized(-p0.v);
     sep = mk3(0, 0, 0);
     nsup = 0;
-    p1 = mpr_support(G1, G2, dir); nsup++;
+    p1 = mpr_support<W>(G1, G2, dir); nsup++;
     if (dot(p1.v, dir) < eps) { sep = dir; return false; }
     dir = cross(p0.v, p1.v);
     if (dot(dir, dir) < eps * eps) {
@@ -570,7 +600,7 @@ __device__ bool mpr_penetration(const Geom &G1, const Geom &G2, float tol, int m
         return true;
     }
     dir = normalized(dir);
-    p2 = mpr_support(G1, G2, dir); nsup++;
+    p2 = mpr_support<W>(G1, G2, dir); nsup++;
     if (dot(p2.v, dir) < eps) { sep = dir; return false; }
     dir = normalized(cross(p1.v - p0.v, p2.v - p0.v));
     {
@@ -580,7 +610,7 @@ __device__ bool mpr_penetration(const Geom &G1, const Geom &G2, float tol, int m
     }
     for (int it = 0;; it++) {
         if (it > 100) return false;
-        p3 = mpr_support(G1, G2, dir); nsup++;
+        p3 = mpr_support<W>(G1, G2, dir); nsup++;
         if (dot(p3.v, dir) < eps) { sep = dir; return false; }
         const bool c1 = dot(cross(p1.v, p3.v), p0.v) < -eps;
         const bool c2 = !c1 && dot(cross(p3.v, p2.v), p0.v) < -eps;
@@ -592,14 +622,14 @@ __device__ bool mpr_penetration(const Geom &G1, const Geom &G2, float tol, int m
     for (int it = 0;; it++) {
         dir = portal_dir(p1, p2, p3);
         if (dot(dir, p1.v) >= -eps) break;
-        v4 = mpr_support(G1, G2, dir); nsup++;
+        v4 = mpr_support<W>(G1, G2, dir); nsup++;
         if (dot(v4.v, dir) < -eps) { sep = dir; return false; }
         if (reach_tol(p1, p2, p3, v4, dir, tol) || it > maxit) return false;
         expand_portal(p0, p1, p2, p3, v4);
     }
     for (int it = 0;; it++) {
         dir = portal_dir(p1, p2, p3);
-        v4 = mpr_support(G1, G2, dir); nsup++;
+        v4 = mpr_support<W>(G1, G2, dir); nsup++;
         if (reach_tol(p1, p2, p3, v4, dir, tol) || it > maxit) {
             v3 pdir;
             bool interior;

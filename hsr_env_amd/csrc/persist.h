@@ -36,43 +36,62 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(DevModel m, DevState s, i
     extern __shared__ __align__(16) float lds[];
     constexpr int EPB = 64 / G;
     const PersistLayout<G> L(m.njmax, s.kstride, m.npair_pad, m.nlink);
-    const int tid = threadIdx.x, g = tid / G, c = tid % G;
-    const int e_raw = blockIdx.x * EPB + g;
-    const bool in_range = e_raw < s.N;
-    const int e = in_range ? e_raw : 0;
+    const int tid0 = threadIdx.x;
     const int N = s.N, nv = m.nv, nq = m.nq, R = L.R, MS = L.MS;
     const int mode = 1, debug = 0;
-    float *E = lds + (size_t)g * L.envf;
-    float *rD = E + L.oRows, *rAref = rD + R, *rJar = rAref + R, *rJv = rJar + R, *rGr = rJv + R, *rDw = rGr + R;
-    float *kAng = E + L.oRows, *kLin = kAng + 3 * nv, *kAnc = kAng + 6 * nv, *lk = kAng + 9 * nv;
-    int *pcnt = reinterpret_cast<int *>(E + L.oCnt);
-    float *M = E + L.oB, *con = E + L.oB;
-    // kinematics scratch inside region B (dead before the solver writes M there)
-    float *xposL = E + L.oB, *xmatL = xposL + 3 * m.nlink, *recL = xmatL + 9 * m.nlink, *qposL = recL + 12 * m.nlink, *qvelL = qposL + G;
-    float *poly = lds + L.oPoly;
-    const bool isdof = c < nv;
+    // everything derived from the lane id is declared through this macro: once for the prologue, once per substep from a
+    // laundered copy of the lane id (so that LLVM does not hoist ~100 loop-invariant addresses out of the substep loop and
+    // then spill them), once for the epilogue
+#define PERSIST_LANE_VIEW(TID)                                                                                              \
+    const int tid = (TID), g = tid / G, c = tid % G;                                                                         \
+    const int e_raw = blockIdx.x * EPB + g;                                                                                  \
+    const bool in_range = e_raw < N;                                                                                         \
+    const int e = in_range ? e_raw : 0;                                                                                      \
+    float *E = lds + (size_t)g * L.envf;                                                                                     \
+    float *rD = E + L.oRows, *rAref = rD + R, *rJar = rAref + R, *rJv = rJar + R, *rGr = rJv + R, *rDw = rGr + R;            \
+    float *kAng = E + L.oRows, *kLin = kAng + 3 * nv, *kAnc = kAng + 6 * nv, *lk = kAng + 9 * nv;                            \
+    int *pcnt = reinterpret_cast<int *>(E + L.oCnt);                                                                         \
+    float *M = E + L.oB, *con = E + L.oB;                                                                                    \
+    /* kinematics scratch inside region B (dead before the solver writes M there) */                                        \
+    float *xposL = E + L.oB, *xmatL = xposL + 3 * m.nlink, *recL = xmatL + 9 * m.nlink, *qposL = recL + 12 * m.nlink, *qvelL = qposL + G; \
+    float *poly = lds + L.oPoly;                                                                                             \
+    const bool isdof = c < nv;                                                                                               \
+    (void)rD; (void)rAref; (void)rJar; (void)rJv; (void)rGr; (void)rDw; (void)kLin; (void)kAnc; (void)lk; (void)pcnt; (void)M; (void)con; \
+    (void)xmatL; (void)qvelL; (void)poly; (void)isdof; (void)e; (void)in_range;
     int bad_acc = 0;
-    __shared__ int sParent[32], sMask[NLMAX], sDepth[NLMAX], sItems[64];
+    __shared__ int sParent[32], sMask[NLMAX], sDepth[NLMAX];
+    __shared__ unsigned short sItems[64];
+    __shared__ unsigned char sMpr[64];
     __shared__ float sMass[NLMAX];
-    if (tid < nv) sParent[tid] = m.dof_parent[tid];
-    if (tid < m.nlink && tid < NLMAX) { sMask[tid] = m.link_dofmask[tid]; sMass[tid] = m.link_mass[tid]; sDepth[tid] = m.link_depth[tid]; }
+    if (tid0 < nv) sParent[tid0] = m.dof_parent[tid0];
+    if (tid0 < m.nlink && tid0 < NLMAX) { sMask[tid0] = m.link_dofmask[tid0]; sMass[tid0] = m.link_mass[tid0]; sDepth[tid0] = m.link_depth[tid0]; }
 
     // ---------------- load the env state once; it lives in registers for the whole env-step
     float qpos_c = 0, qvel_c = 0, warm_c = 0;          // qpos_c: lane = qpos index; qvel_c / warm_c: lane = dof
-    bool done = !in_range || s.done[e] != 0;
-    if (c < nq) qpos_c = s.qpos[(size_t)c * N + e];
-    if (isdof) { qvel_c = s.qvel[(size_t)c * N + e]; warm_c = s.warm[(size_t)c * N + e]; }
-    const v3 goal = mk3(s.mocap[e], s.mocap[N + e], s.mocap[2 * N + e]);
-    float time_e = s.time[e];
+    bool done;
+    v3 goal;
+    float time_e;
     int nsteps_e = 0;
+    {
+        PERSIST_LANE_VIEW(tid0)
+        done = !in_range || s.done[e] != 0;
+        if (c < nq) qpos_c = s.qpos[(size_t)c * N + e];
+        if (isdof) { qvel_c = s.qvel[(size_t)c * N + e]; warm_c = s.warm[(size_t)c * N + e]; }
+        goal = mk3(s.mocap[e], s.mocap[N + e], s.mocap[2 * N + e]);
+        time_e = s.time[e];
+    }
     const int goal_link = (goal_body >= 0 && !m.body_mocap[goal_body]) ? m.body_link[goal_body] : -1;
     const v3 goal_off = goal_body >= 0 ? ld3(m.body_pos, goal_body) : mk3(0, 0, 0);
     PHASE_T0();
 
     for (int sub = 0; sub < n_substeps; sub++) {
+        int tid_l = tid0;
+        asm volatile("" : "+v"(tid_l));
+        PERSIST_LANE_VIEW(tid_l)
         const bool valid = !done;
         if (!__syncthreads_or(valid)) break;
         int bad = 0;                 // per substep; only a live env's flag is kept
+        asm volatile("" ::: "memory");   // model constants are re-read (L2 hits) every substep instead of living in - and spilling from - registers
         // ---------------- K: kinematics of this env by lane 0 of its group, on LDS views
         qposL[c] = qpos_c; qvelL[c] = qvel_c;
         __syncthreads();
@@ -127,15 +146,17 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(DevModel m, DevState s, i
                     pass = pair_cull_r(G1, G2, rec[13], rec[14]);
                 }
                 const unsigned long long bal = __ballot(pass);
-                if (pass) { const int k = nitems + __popcll(bal & ((1ull << tid) - 1ull)); if (k < 64) sItems[k] = (g << 16) | p; }
+                if (pass) { const int k = nitems + __popcll(bal & ((1ull << tid) - 1ull)); if (k < 64) sItems[k] = (unsigned short)((g << 14) | p); }
                 nitems += __popcll(bal);
             }
+            DBGCNT(2, nitems);
+            PHASE(19);
             if (nitems > 64) nitems = 64;                          // more than 64 surviving pairs in 4 envs: never observed; extra ones are dropped
             __syncthreads();
             {
                 const bool act = tid < nitems;
                 const int it = act ? sItems[tid] : 0;
-                const int ig = it >> 16, p = it & 0xffff;
+                const int ig = it >> 14, p = it & 0x3fff;
                 float *Ei = lds + (size_t)ig * L.envf;
                 const View vx{Ei + L.oB, 1}, vm{Ei + L.oB + 3 * m.nlink, 1};
                 const int ei = blockIdx.x * EPB + ig;
@@ -145,20 +166,53 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(DevModel m, DevState s, i
                 const int fn = act ? (int)rec[2] : -1;
                 Geom G1, G2;
                 if (act) { G1 = geom_from_rec(rec, 0, vx, vm, m.mesh_vert4); G2 = geom_from_rec(rec, 1, vx, vm, m.mesh_vert4); }
+                PHASE(20);
                 if (fn == FN_PLANE_BOX) collide_plane_box(G1, G2, out);
                 else if (fn == FN_PLANE_CONVEX) collide_plane_convex(G1, G2, out);
-                else if (fn == FN_CONVEX) {
-                    float *sx = s.sepax + (size_t)(3 * p) * N + ei;
-                    const v3 d = mk3(sx[0], sx[N], sx[2 * (size_t)N]);
-                    bool still = false;
-                    if (d.x != 0.f || d.y != 0.f || d.z != 0.f) still = dot(support(G1, d) - support(G2, -d), d) < -1e-7f;
-                    if (!still) {
-                        float depth; v3 dir, pos, sep;
-                        int nsup = 0;
-                        if (mpr_penetration(G1, G2, m.mpr_tolerance, m.mpr_iterations, depth, dir, pos, sep, nsup)) { out.add(pos, dir, -depth); sep = mk3(0, 0, 0); }
-                        sx[0] = sep.x; sx[N] = sep.y; sx[2 * (size_t)N] = sep.z;
+                PHASE(21);
+                // convex pairs (MPR): one work item per MW-lane sub-group, the lanes share the hull scans of the support function
+                {
+                    constexpr int MW = 8;
+                    const bool cv = fn == FN_CONVEX;
+                    const unsigned long long cbal = __ballot(cv);
+                    if (cv) sMpr[__popcll(cbal & ((1ull << tid) - 1ull))] = (unsigned char)tid;
+                    const int ncv = __popcll(cbal);
+                    __syncthreads();
+                    for (int r0 = 0; r0 < ncv; r0 += 64 / MW) {
+                        const int k = r0 + tid / MW;
+                        if (k < ncv) {
+                            const int src = sMpr[k];
+                            const int it2 = sItems[src];
+                            const int ig2 = it2 >> 14, p2 = it2 & 0x3fff;
+                            float *E2 = lds + (size_t)ig2 * L.envf;
+                            const View vx2{E2 + L.oB, 1}, vm2{E2 + L.oB + 3 * m.nlink, 1};
+                            const int e2 = blockIdx.x * EPB + ig2;
+                            const float *rec2 = m.pair_geo + 64 * p2;
+                            const Geom H1 = geom_from_rec(rec2, 0, vx2, vm2, m.mesh_vert4), H2 = geom_from_rec(rec2, 1, vx2, vm2, m.mesh_vert4);
+                            float *sx = s.sepax + (size_t)(3 * p2) * N + e2;
+                            const v3 d = mk3(sx[0], sx[N], sx[2 * (size_t)N]);
+                            bool still = false;
+                            if (d.x != 0.f || d.y != 0.f || d.z != 0.f) still = dot(support<MW>(H1, d) - support<MW>(H2, -d), d) < -1e-7f;
+                            int cnt2 = 0;
+                            if (!still) {
+                                float depth; v3 dir, pos, sep;
+                                int nsup = 0;
+                                const bool hit = mpr_penetration<MW>(H1, H2, m.mpr_tolerance, m.mpr_iterations, depth, dir, pos, sep, nsup);
+                                if ((tid & (MW - 1)) == 0) {
+                                    if (hit) {
+                                        ContactOut o2;
+                                        o2.con = s.con + (size_t)e2 * m.nslot * 8; o2.slot = (int)rec2[3]; o2.maxcnt = (int)rec2[4]; o2.cnt = 0;
+                                        o2.add(pos, dir, -depth); sep = mk3(0, 0, 0);
+                                        cnt2 = o2.cnt;
+                                    }
+                                    sx[0] = sep.x; sx[N] = sep.y; sx[2 * (size_t)N] = sep.z;
+                                }
+                            }
+                            if ((tid & (MW - 1)) == 0) reinterpret_cast<int *>(E2 + L.oCnt)[p2] = cnt2;
+                        }
                     }
                 }
+                PHASE(22);
                 // box-box needs LDS polygon scratch: at most 8 lanes of the wave run it at a time
                 {
                     const bool bb = fn == FN_BOX_BOX;
@@ -172,7 +226,8 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(DevModel m, DevState s, i
                         pend = t;
                     }
                 }
-                if (act) reinterpret_cast<int *>(Ei + L.oCnt)[p] = out.cnt;
+                PHASE(23);
+                if (act && fn != FN_CONVEX) reinterpret_cast<int *>(Ei + L.oCnt)[p] = out.cnt;
             }
         }
         __threadfence_block();       // contact records written to global by other lanes of this workgroup
@@ -249,6 +304,7 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(DevModel m, DevState s, i
         }
     }
     // ---------------- write the state back (struct-of-arrays)
+    PERSIST_LANE_VIEW(tid0)
     if (in_range && !(s.done[e] != 0 && nsteps_e == 0)) {
         if (c < nq) s.qpos[(size_t)c * N + e] = qpos_c;
         if (isdof) { s.qvel[(size_t)c * N + e] = qvel_c; s.warm[(size_t)c * N + e] = warm_c; }
@@ -260,4 +316,5 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(DevModel m, DevState s, i
         }
     }
     PHASE_FLUSH();
+#undef PERSIST_LANE_VIEW
 }

@@ -1,0 +1,45 @@
+"""Diagnostic: when does each workgroup of the persistent kernel start and end, and where (needs libhsrsim_timing.so)."""
+import ctypes as C, sys, numpy as np
+sys.path.insert(0, '.')
+from hsr_env_amd.compiler import load_config
+from hsr_env_amd import sim as hs
+from bench import sample_inputs
+m = load_config('cfg3'); n = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
+q0, goal = sample_inputs(m, n, 0, 0)
+sim = hs.BatchSim(m, n); sim.set_graph(False)
+sim.reset(qpos0=q0, mocap=goal)
+rng = np.random.default_rng(1)
+for k in range(3):
+    ctrl = rng.uniform(m.act_ctrlrange[:, 0], m.act_ctrlrange[:, 1], (n, m.nu)).astype(np.float32)
+    sim.step(ctrl, 300, m.body_id('block0'), 0.05)
+nb = n // 4
+L = sim._L
+L.hsr_batch_block_times.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong), C.c_int]
+buf = (C.c_ulonglong * (8 * nb))()
+L.hsr_batch_block_times(sim._b, buf, nb)
+a = np.array(list(buf), dtype=np.int64).reshape(nb, 8)
+t0 = a[:, 0].min()
+st = (a[:, 0] - t0) / 100.0; en = (a[:, 1] - t0) / 100.0       # us
+print('blocks', nb, 'kernel span %.1f ms' % (en.max() / 1e3))
+print('start  percentiles us (0,25,50,75,90,100):', np.percentile(st, [0, 25, 50, 75, 90, 100]).round(0))
+print('end    percentiles us:', np.percentile(en, [0, 25, 50, 75, 90, 100]).round(0))
+print('life   percentiles us:', np.percentile(en - st, [0, 25, 50, 75, 90, 100]).round(0))
+print('blocks started within 100 us of kernel start:', int((st < 100).sum()))
+hw = a[:, 2]; xcc = a[:, 3] & 0xf
+cu = (hw >> 8) & 0xf; sh = (hw >> 12) & 1; se = (hw >> 13) & 7; simd = (hw >> 4) & 3; wv = hw & 0xf
+cuid = ((xcc * 8 + se) * 2 + sh) * 16 + cu
+first = st < 100
+print('distinct CUs', len(np.unique(cuid)), ' first-round blocks per CU: min %d max %d' % (np.bincount(cuid[first]).min(), np.bincount(cuid[first]).max()))
+print('first-round waves per (CU, SIMD):', np.bincount(np.bincount(cuid[first] * 4 + simd[first])))
+print('wave slot ids used:', np.unique(wv))
+
+life = en - st
+o = np.argsort(life)
+print('newton trips / substep: mean %.2f, slowest 10 blocks %s, fastest 10 %s' % (a[:, 4].mean() / 300, (a[o[-10:], 4] / 300).round(2), (a[o[:10], 4] / 300).round(2)))
+print('ls trips (env 0 of block) / substep: mean %.2f, slowest 10 %s' % (a[:, 5].mean() / 300, (a[o[-10:], 5] / 300).round(2)))
+print('narrowphase items / substep: mean %.2f, slowest 10 %s' % (a[:, 6].mean() / 300, (a[o[-10:], 6] / 300).round(2)))
+print('nefc sum / substep: mean %.2f, slowest 10 %s' % (a[:, 7].mean() / 300, (a[o[-10:], 7] / 300).round(2)))
+print('corr(life, newton) %.3f  corr(life, items) %.3f corr(life, nefc) %.3f' % (np.corrcoef(life, a[:, 4])[0, 1], np.corrcoef(life, a[:, 6])[0, 1], np.corrcoef(life, a[:, 7])[0, 1]))
+A = np.stack([np.ones(nb), a[:, 4], a[:, 6], a[:, 7]], 1).astype(np.float64)
+coef = np.linalg.lstsq(A, life * 300 / 300, rcond=None)[0]
+print('life us ~ %.0f + %.2f * newton_trips + %.2f * items + %.2f * nefc' % tuple(coef))

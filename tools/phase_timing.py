@@ -20,9 +20,9 @@ L.hsr_batch_phase_cycles(sim._b, buf)
 ctrl = rng.uniform(m.act_ctrlrange[:, 0], m.act_ctrlrange[:, 1], (n, m.nu)).astype(np.float32)
 sim.step(ctrl, 300, m.body_id('block0'), 0.05)
 L.hsr_batch_phase_cycles(sim._b, buf)
-v = np.array(list(buf), dtype=np.float64)[:19]
+v = np.array(list(buf), dtype=np.float64)[:24]
 names = ['A load', 'B/C M+bias', 'D chol M+solve', 'E1-2 limits+compact', 'E3 contact rec', 'E4-5 J rows', 'F0 warm evals', 'F grad',
-         'F hess', 'F chol+solve', 'F ls setup+ls', 'F update+eval', 'qfc..stores+G chol(12)', 'G solve..stores+tail(13)', 'loop exit+qfc jt_force(14)', 'G chol only(15)', 'K kinematics(16)', 'C collision(17)', 'integrate+regs(18)']
+         'F hess', 'F chol+solve', 'F ls setup+ls', 'F update+eval', 'qfc..stores+G chol(12)', 'G solve..stores+tail(13)', 'loop exit+qfc jt_force(14)', 'G chol only(15)', 'K kinematics(16)', 'C collision(17)', 'integrate+regs(18)', 'C pass1 cull(19)', 'C item setup(20)', 'C plane(21)', 'C mpr(22)', 'C boxbox(23)']
 tot = v.sum()
 for nm, x in zip(names, v):
     print(f'{nm:22s} {x / tot * 100:6.2f} %   {x / (2048 * 300):9.0f} cyc/block/substep')
