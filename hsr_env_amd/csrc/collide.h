@@ -695,24 +695,49 @@ __device__ __forceinline__ bool obb_overlap(const Geom &A, const Geom &B) {
     return !sep;
 }
 
-// Geom w (0 / 1) of a packed pair record (DevModel::pair_geo) placed by the link poses in xpos / xmat
-__device__ __forceinline__ Geom geom_from_rec(const float *rec, int w, View xpos, View xmat, const float4 *mesh_vert4) {
-    Geom G;
-    const float *o = rec + 16 + 21 * w;
-    const int l = (int)rec[5 + w];
+// world placement of geom gi (16 floats: pos3 mat9 box-centre3 -) from the link poses; rec = DevModel::geom_rec + 32 gi
+__device__ __forceinline__ void geom_place(const float *rec, View xpos, View xmat, float *out) {
+    const int l = (int)rec[0];
     const m3 R = xmat.getm(l);
     m3 lm;
 #pragma unroll
-    for (int k = 0; k < 9; k++) lm.a[k] = o[3 + k];
-    G.pos = xpos.get3(l) + mulmv(R, mk3(o[0], o[1], o[2]));
-    G.mat = mulmm(R, lm);
-    G.type = (int)rec[7 + w];
-    G.size = mk3(o[12], o[13], o[14]);
-    G.bc = G.pos + mulmv(G.mat, mk3(o[15], o[16], o[17]));
-    G.bh = mk3(o[18], o[19], o[20]);
-    G.nvert = (int)rec[11 + w];
-    G.verts = mesh_vert4 + (int)rec[9 + w];
+    for (int k = 0; k < 9; k++) lm.a[k] = rec[5 + k];
+    const v3 pos = xpos.get3(l) + mulmv(R, mk3(rec[2], rec[3], rec[4]));
+    const m3 mat = mulmm(R, lm);
+    const v3 bc = pos + mulmv(mat, mk3(rec[17], rec[18], rec[19]));
+    out[0] = pos.x; out[1] = pos.y; out[2] = pos.z;
+#pragma unroll
+    for (int k = 0; k < 9; k++) out[3 + k] = mat.a[k];
+    out[12] = bc.x; out[13] = bc.y; out[14] = bc.z;
+}
+// Geom from its cached world placement w (LDS) and its constant record
+__device__ __forceinline__ Geom geom_cached(const float *w, const float *rec, const float4 *mesh_vert4) {
+    Geom G;
+    G.pos = mk3(w[0], w[1], w[2]);
+#pragma unroll
+    for (int k = 0; k < 9; k++) G.mat.a[k] = w[3 + k];
+    G.bc = mk3(w[12], w[13], w[14]);
+    G.type = (int)rec[1];
+    G.size = mk3(rec[14], rec[15], rec[16]);
+    G.bh = mk3(rec[20], rec[21], rec[22]);
+    G.nvert = (int)rec[23];
+    G.verts = mesh_vert4 + (int)rec[24];
     return G;
+}
+// the culls of pair_cull_r split in two: bounding spheres (positions only), then oriented boxes
+__device__ __forceinline__ bool pair_cull_sphere(int type1, const float *w1, const float *w2, float rb1, float rb2) {
+    const v3 r = mk3(w2[0] - w1[0], w2[1] - w1[1], w2[2] - w1[2]);
+    if (type1 == GEOM_PLANE) return dot(r, mk3(w1[5], w1[8], w1[11])) <= rb2;
+    const float b = rb1 + rb2;
+    return dot(r, r) <= b * b;
+}
+__device__ __forceinline__ bool pair_cull_box(const Geom &G1, const Geom &G2, float rb1, float rb2) {
+    if (G1.type == GEOM_PLANE) {
+        const v3 n = col(G1.mat, 2);
+        return dot(G2.bc - G1.pos, n) - (fabsf(dot(n, col(G2.mat, 0))) * G2.bh.x + fabsf(dot(n, col(G2.mat, 1))) * G2.bh.y + fabsf(dot(n, col(G2.mat, 2))) * G2.bh.z) <= 0.f;
+    }
+    if (!(sphere_hits_obb(G2.pos, rb2, G1) && sphere_hits_obb(G1.pos, rb1, G2))) return false;
+    return obb_overlap(G1, G2);
 }
 __device__ __forceinline__ bool pair_cull_r(const Geom &G1, const Geom &G2, float rb1, float rb2) {
     if (G1.type == GEOM_PLANE) {

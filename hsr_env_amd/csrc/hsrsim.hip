@@ -394,30 +394,31 @@ extern "C" int hsr_batch_create(const hsr_model *m, int n_envs, int device_id, h
         HIPCHK(hipMemcpy(dda, da.data(), da.size() * sizeof(int), hipMemcpyHostToDevice));
         d.dof_act = dda;
     }
-    {   // packed per-pair collision records: [0..15] ids / sizes, [16..36] geom1 (lpos3 lmat9 size3 aabb6), [37..57] geom2
+    {   // packed collision constants: one 32-float record per geom, one 8-float record per candidate pair
         const int *g1 = m->i32("pair_geom1"), *g2 = m->i32("pair_geom2"), *fn = m->i32("pair_fn"), *sl = m->i32("pair_slot");
         const int *gl = m->i32("geom_link"), *gt = m->i32("geom_type"), *ma = m->i32("geom_meshadr"), *mn = m->i32("geom_meshnum");
         const double *gp = m->f64("geom_pos"), *gq = m->f64("geom_quat"), *gs = m->f64("geom_size"), *gb = m->f64("geom_aabb"), *gr = m->f64("geom_rbound");
-        std::vector<float> rec((size_t)std::max(d.npair, 1) * 64, 0.f);
+        std::vector<float> rec((size_t)std::max(d.npair, 1) * 8, 0.f), grec((size_t)std::max(d.ngeom, 1) * 32, 0.f);
         for (int p = 0; p < d.npair; p++) {
-            float *r = rec.data() + 64 * p;
-            const int a = g1[p], c2 = g2[p];
-            r[0] = (float)a; r[1] = (float)c2; r[2] = (float)fn[p]; r[3] = (float)sl[p]; r[4] = (float)(sl[p + 1] - sl[p]);
-            r[5] = (float)gl[a]; r[6] = (float)gl[c2]; r[7] = (float)gt[a]; r[8] = (float)gt[c2];
-            r[9] = (float)ma[a]; r[10] = (float)ma[c2]; r[11] = (float)mn[a]; r[12] = (float)mn[c2];
-            r[13] = (float)gr[a]; r[14] = (float)gr[c2];
-            for (int w = 0; w < 2; w++) {
-                const int gg = w == 0 ? a : c2;
-                float *o = r + 16 + 21 * w;
-                for (int k = 0; k < 3; k++) o[k] = (float)gp[3 * gg + k];
-                quat2mat_h(gq + 4 * gg, o + 3);
-                for (int k = 0; k < 3; k++) o[12 + k] = (float)gs[3 * gg + k];
-                for (int k = 0; k < 6; k++) o[15 + k] = (float)gb[6 * gg + k];
-            }
+            float *r = rec.data() + 8 * p;
+            r[0] = (float)g1[p]; r[1] = (float)g2[p]; r[2] = (float)gr[g1[p]]; r[3] = (float)gr[g2[p]];
+            r[4] = (float)fn[p]; r[5] = (float)sl[p]; r[6] = (float)(sl[p + 1] - sl[p]); r[7] = (float)gt[g1[p]];
+        }
+        for (int gg = 0; gg < d.ngeom; gg++) {
+            float *o = grec.data() + 32 * gg;
+            o[0] = (float)gl[gg]; o[1] = (float)gt[gg];
+            for (int k = 0; k < 3; k++) o[2 + k] = (float)gp[3 * gg + k];
+            quat2mat_h(gq + 4 * gg, o + 5);
+            for (int k = 0; k < 3; k++) o[14 + k] = (float)gs[3 * gg + k];
+            for (int k = 0; k < 6; k++) o[17 + k] = (float)gb[6 * gg + k];
+            o[23] = (float)mn[gg]; o[24] = (float)ma[gg]; o[25] = (float)gr[gg];
         }
         float *dg; if ((rc = dalloc(b, &dg, rec.size()))) return rc;
         HIPCHK(hipMemcpy(dg, rec.data(), rec.size() * sizeof(float), hipMemcpyHostToDevice));
         d.pair_geo = dg;
+        if ((rc = dalloc(b, &dg, grec.size()))) return rc;
+        HIPCHK(hipMemcpy(dg, grec.data(), grec.size() * sizeof(float), hipMemcpyHostToDevice));
+        d.geom_rec = dg;
     }
     if ((rc = upload_mats(b, &d.link_mat, m, "link_quat"))) return rc;
     if ((rc = upload_mats(b, &d.geom_mat, m, "geom_quat"))) return rc;
@@ -487,7 +488,7 @@ extern "C" int hsr_batch_create(const hsr_model *m, int n_envs, int device_id, h
     if (b->solver == 2) {
         const char *pe = getenv("HSR_PERSIST");
         b->persist = !(pe && strcmp(pe, "0") == 0);
-        const int total = b->group == 16 ? PersistLayout<16>(d.njmax, b->ds.kstride, d.npair_pad, d.nlink).total : PersistLayout<32>(d.njmax, b->ds.kstride, d.npair_pad, d.nlink).total;
+        const int total = b->group == 16 ? PersistLayout<16>(d.njmax, b->ds.kstride, d.npair_pad, d.nlink, d.ngeom).total : PersistLayout<32>(d.njmax, b->ds.kstride, d.npair_pad, d.nlink, d.ngeom).total;
         b->persist_lds_bytes = (size_t)total * sizeof(float);
         {   // KinLane preloads at most three scalar joints per body
             const int *dn = m->i32("link_dofnum"), *lf = m->i32("link_free");

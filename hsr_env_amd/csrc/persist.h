@@ -16,18 +16,18 @@
 
 template <int G> struct PersistLayout {
     int R, MS, oRows, oCnt, oB, envf, oPoly, total;
-    __host__ __device__ PersistLayout(int rows, int kstride, int npair_pad, int nlink) {
+    __host__ __device__ PersistLayout(int rows, int kstride, int npair_pad, int nlink, int ngeom) {
         R = rows; MS = G + 1;
         int a = 6 * R > kstride ? 6 * R : kstride;                            // row scalars / kin record
         oRows = 0; oCnt = (a + 3) & ~3;                                       // pair counts survive phases A-D next to the kin record
         a = oCnt + npair_pad;
         int b = G * MS > C2_SIZE * G ? G * MS : C2_SIZE * G;                  // inertia matrix / contact records ...
-        const int kin_tmp = 24 * nlink + 2 * G;                                // ... or link poses + recursion scratch + qpos/qvel staging
+        const int kin_tmp = 24 * nlink + 2 * G + 16 * ngeom;                   // ... or link poses + recursion scratch + qpos/qvel staging + geom placements
         if (kin_tmp > b) b = kin_tmp;
         oB = (a + 3) & ~3;
         envf = (oB + b + 3) & ~3;
-        oPoly = envf * (64 / G);                                               // box-box polygon scratch: 8 slots of 48 floats per wave
-        total = oPoly + 8 * 48;
+        oPoly = envf * (64 / G);                                               // box-box polygon scratch: 4 slots of 48 floats per wave
+        total = oPoly + 4 * 48;
     }
 };
 
@@ -35,7 +35,7 @@ template <int G>
 __global__ void __launch_bounds__(64, 2) k_env_step_mf(DevModel m, DevState s, int n_substeps, int goal_body, float geofence) {
     extern __shared__ __align__(16) float lds[];
     constexpr int EPB = 64 / G;
-    const PersistLayout<G> L(m.njmax, s.kstride, m.npair_pad, m.nlink);
+    const PersistLayout<G> L(m.njmax, s.kstride, m.npair_pad, m.nlink, m.ngeom);
     const int tid0 = threadIdx.x;
     const int N = s.N, nv = m.nv, nq = m.nq, R = L.R, MS = L.MS;
     const int mode = 1, debug = 0;
@@ -62,6 +62,7 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(DevModel m, DevState s, i
     __shared__ int sParent[32], sMask[NLMAX], sDepth[NLMAX];
     __shared__ unsigned short sItems[64];
     __shared__ unsigned char sMpr[64];
+    __shared__ unsigned short sCand[128];
     __shared__ float sMass[NLMAX];
     if (tid0 < nv) sParent[tid0] = m.dof_parent[tid0];
     if (tid0 < m.nlink && tid0 < NLMAX) { sMask[tid0] = m.link_dofmask[tid0]; sMass[tid0] = m.link_mass[tid0]; sDepth[tid0] = m.link_depth[tid0]; }
@@ -129,43 +130,73 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(DevModel m, DevState s, i
             for (int i = c; i < 9 * m.nlink; i += G) s.xmat[(size_t)i * N + e] = xmatL[i];
         }
         // ---------------- C: collision
-        // pass 1, lane = candidate pair of its own env: bounding culls only; survivors are appended to a workgroup work
-        // list with wave ballots.  pass 2, lane = work item of ANY env of the workgroup: the narrowphase runs with the
-        // survivors of all pairs and envs side by side instead of one sparse pass per 16 pairs.
+        // G: lane = geom, world placement of every geom once per substep (LDS, next to the link poses)
+        // 1: lane = candidate pair of its own env, bounding spheres; survivors -> workgroup candidate list (wave ballots)
+        // 2: lane = candidate of ANY env, oriented-box culls; survivors -> work items
+        // 3: lane (or 8-lane sub-group for MPR) = work item: the narrowphases of all envs of the workgroup side by side
         {
+            float *gw = qvelL + G;
+            const int oGw = (int)(gw - E);
+            if (valid) for (int gi = c; gi < m.ngeom; gi += G) geom_place(m.geom_rec + 32 * gi, View{xposL, 1}, View{xmatL, 1}, gw + 16 * gi);
             for (int p0 = 0; p0 < m.npair_pad; p0 += G) { const int p = p0 + c; if (p < m.npair_pad) pcnt[p] = 0; }
-            int nitems = 0;                                        // wave-uniform
-            for (int p0 = 0; p0 < m.npair; p0 += G) {
-                const int p = p0 + c;
-                const bool have = valid && p < m.npair;
+            __syncthreads();
+            const float4 *pg4 = reinterpret_cast<const float4 *>(m.pair_geo);
+            int ncand = 0, nitems = 0;                             // wave-uniform
+            // level 2 over the first min(ncand, 64) candidates of the list; the rest moves to the front
+            auto box_round = [&]() {
+                const int take = ncand < 64 ? ncand : 64;
                 bool pass = false;
-                if (have) {
-                    const float *rec = m.pair_geo + 64 * p;
-                    const Geom G1 = geom_from_rec(rec, 0, View{xposL, 1}, View{xmatL, 1}, m.mesh_vert4);
-                    const Geom G2 = geom_from_rec(rec, 1, View{xposL, 1}, View{xmatL, 1}, m.mesh_vert4);
-                    pass = pair_cull_r(G1, G2, rec[13], rec[14]);
+                int it = 0;
+                if (tid < take) {
+                    it = sCand[tid];
+                    const float *gwi = lds + (size_t)(it >> 14) * L.envf + oGw;
+                    const float4 a = pg4[2 * (it & 0x3fff)];
+                    const int g1 = (int)a.x, g2 = (int)a.y;
+                    pass = pair_cull_box(geom_cached(gwi + 16 * g1, m.geom_rec + 32 * g1, m.mesh_vert4), geom_cached(gwi + 16 * g2, m.geom_rec + 32 * g2, m.mesh_vert4), a.z, a.w);
                 }
                 const unsigned long long bal = __ballot(pass);
-                if (pass) { const int k = nitems + __popcll(bal & ((1ull << tid) - 1ull)); if (k < 64) sItems[k] = (unsigned short)((g << 14) | p); }
+                if (pass) { const int kk = nitems + __popcll(bal & ((1ull << tid) - 1ull)); if (kk < 64) sItems[kk] = (unsigned short)it; }
                 nitems += __popcll(bal);
+                const int rest = ncand - take;
+                unsigned short mv = 0;
+                if (tid < rest) mv = sCand[take + tid];
+                __syncthreads();
+                if (tid < rest) sCand[tid] = mv;
+                __syncthreads();
+                ncand = rest;
+            };
+            for (int p0 = 0; p0 < m.npair; p0 += G) {
+                const int p = p0 + c;
+                bool pass = false;
+                if (valid && p < m.npair) {
+                    const float4 a = pg4[2 * p];
+                    pass = pair_cull_sphere((int)m.pair_geo[8 * p + 7], gw + 16 * (int)a.x, gw + 16 * (int)a.y, a.z, a.w);
+                }
+                const unsigned long long bal = __ballot(pass);
+                if (pass) sCand[ncand + __popcll(bal & ((1ull << tid) - 1ull))] = (unsigned short)((g << 14) | p);   // ncand < 64 here
+                ncand += __popcll(bal);
+                DBGCNT(1, __popcll(bal));
+                if (ncand >= 64) { __syncthreads(); box_round(); }
             }
-            DBGCNT(2, nitems);
+            __syncthreads();
             PHASE(19);
-            if (nitems > 64) nitems = 64;                          // more than 64 surviving pairs in 4 envs: never observed; extra ones are dropped
+            while (ncand > 0) box_round();
+            if (nitems > 64) bad = 1;                              // more than 64 surviving pairs in one workgroup: contacts would be dropped
+            DBGCNT(2, nitems);
+            if (nitems > 64) nitems = 64;
             __syncthreads();
             {
                 const bool act = tid < nitems;
                 const int it = act ? sItems[tid] : 0;
                 const int ig = it >> 14, p = it & 0x3fff;
                 float *Ei = lds + (size_t)ig * L.envf;
-                const View vx{Ei + L.oB, 1}, vm{Ei + L.oB + 3 * m.nlink, 1};
                 const int ei = blockIdx.x * EPB + ig;
-                const float *rec = m.pair_geo + 64 * p;
+                const float4 pa = pg4[2 * p], pb = pg4[2 * p + 1];
                 ContactOut out;
-                out.con = s.con + (size_t)ei * m.nslot * 8; out.slot = (int)rec[3]; out.maxcnt = (int)rec[4]; out.cnt = 0;
-                const int fn = act ? (int)rec[2] : -1;
+                out.con = s.con + (size_t)ei * m.nslot * 8; out.slot = (int)pb.y; out.maxcnt = (int)pb.z; out.cnt = 0;
+                const int fn = act ? (int)pb.x : -1;
                 Geom G1, G2;
-                if (act) { G1 = geom_from_rec(rec, 0, vx, vm, m.mesh_vert4); G2 = geom_from_rec(rec, 1, vx, vm, m.mesh_vert4); }
+                if (act) { G1 = geom_cached(Ei + oGw + 16 * (int)pa.x, m.geom_rec + 32 * (int)pa.x, m.mesh_vert4); G2 = geom_cached(Ei + oGw + 16 * (int)pa.y, m.geom_rec + 32 * (int)pa.y, m.mesh_vert4); }
                 PHASE(20);
                 if (fn == FN_PLANE_BOX) collide_plane_box(G1, G2, out);
                 else if (fn == FN_PLANE_CONVEX) collide_plane_convex(G1, G2, out);
@@ -185,10 +216,10 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(DevModel m, DevState s, i
                             const int it2 = sItems[src];
                             const int ig2 = it2 >> 14, p2 = it2 & 0x3fff;
                             float *E2 = lds + (size_t)ig2 * L.envf;
-                            const View vx2{E2 + L.oB, 1}, vm2{E2 + L.oB + 3 * m.nlink, 1};
                             const int e2 = blockIdx.x * EPB + ig2;
-                            const float *rec2 = m.pair_geo + 64 * p2;
-                            const Geom H1 = geom_from_rec(rec2, 0, vx2, vm2, m.mesh_vert4), H2 = geom_from_rec(rec2, 1, vx2, vm2, m.mesh_vert4);
+                            const float4 qa = pg4[2 * p2], qb = pg4[2 * p2 + 1];
+                            const Geom H1 = geom_cached(E2 + oGw + 16 * (int)qa.x, m.geom_rec + 32 * (int)qa.x, m.mesh_vert4);
+                            const Geom H2 = geom_cached(E2 + oGw + 16 * (int)qa.y, m.geom_rec + 32 * (int)qa.y, m.mesh_vert4);
                             float *sx = s.sepax + (size_t)(3 * p2) * N + e2;
                             const v3 d = mk3(sx[0], sx[N], sx[2 * (size_t)N]);
                             bool still = false;
@@ -201,7 +232,7 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(DevModel m, DevState s, i
                                 if ((tid & (MW - 1)) == 0) {
                                     if (hit) {
                                         ContactOut o2;
-                                        o2.con = s.con + (size_t)e2 * m.nslot * 8; o2.slot = (int)rec2[3]; o2.maxcnt = (int)rec2[4]; o2.cnt = 0;
+                                        o2.con = s.con + (size_t)e2 * m.nslot * 8; o2.slot = (int)qb.y; o2.maxcnt = (int)qb.z; o2.cnt = 0;
                                         o2.add(pos, dir, -depth); sep = mk3(0, 0, 0);
                                         cnt2 = o2.cnt;
                                     }
@@ -213,16 +244,16 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(DevModel m, DevState s, i
                     }
                 }
                 PHASE(22);
-                // box-box needs LDS polygon scratch: at most 8 lanes of the wave run it at a time
+                // box-box needs LDS polygon scratch: at most 4 lanes of the wave run it at a time
                 {
                     const bool bb = fn == FN_BOX_BOX;
                     unsigned long long pend = __ballot(bb);
                     while (pend) {
                         const int rank = __popcll(pend & ((1ull << tid) - 1ull));
-                        const bool mine = bb && ((pend >> tid) & 1ull) && rank < 8;
+                        const bool mine = bb && ((pend >> tid) & 1ull) && rank < 4;
                         if (mine) collide_box_box_slot(G1, G2, out, poly + 48 * rank);
                         unsigned long long t = pend; int k = 0;
-                        while (t && k < 8) { t &= t - 1; k++; }
+                        while (t && k < 4) { t &= t - 1; k++; }
                         pend = t;
                     }
                 }
