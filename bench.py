@@ -53,24 +53,41 @@ def sample_inputs(m, n, seed, offset):
     return q.astype(np.float32), goal.astype(np.float32)
 
 
+def host_cores():
+    """Threads this process may really use: the affinity mask capped by the cgroup CPU quota."""
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            cores = max(1, min(cores, int(np.ceil(int(quota) / int(period)))))
+    except (OSError, ValueError):
+        pass
+    return cores
+
+
 def cpu_baseline(m, q0, goal, ctrl, cores):
-    """Oracle (fp64 C restatement, OpenMP over envs) on the host cores, bounded sample of the same
-    workload: the first min(N, 64*cores) envs, as many env-steps as fit in ~12 s."""
+    """Oracle (fp64 C restatement, OpenMP over envs) on the host cores, bounded sample of the same workload:
+    a calibration pass on 8 envs per thread sizes the sample (first n envs, r env-steps) to about 12 s."""
     from oracle import oracle as orc
-    n = min(q0.shape[0], 64 * cores)
-    qpos = q0[:n].astype(np.float64).copy(); qvel = np.zeros((n, m.nv)); warm = np.zeros((n, m.nv))
-    mocap = goal[:n].astype(np.float64).copy()
     bid = m.body_id("block0") if "block0" in m.names["body"] else -1
-    t0 = time.perf_counter()
-    orc.batch_env_step(m, qpos, qvel, warm, ctrl[0][:n].astype(np.float64).copy(), mocap, STEPS_PER_ACTION, bid, GEOFENCE, cores)
-    t1 = time.perf_counter() - t0
-    reps = int(max(1, min(len(ctrl) - 1, 12.0 / max(t1, 1e-3) - 1)))
-    t0 = time.perf_counter()
-    for k in range(reps):
-        orc.batch_env_step(m, qpos, qvel, warm, ctrl[1 + k][:n].astype(np.float64).copy(), mocap, STEPS_PER_ACTION, bid, GEOFENCE, cores)
-    dt = time.perf_counter() - t0
+
+    def run(n, reps):
+        qpos = q0[:n].astype(np.float64).copy(); qvel = np.zeros((n, m.nv)); warm = np.zeros((n, m.nv))
+        mocap = goal[:n].astype(np.float64).copy()
+        t0 = time.perf_counter()
+        for k in range(reps):
+            orc.batch_env_step(m, qpos, qvel, warm, ctrl[k % len(ctrl)][:n].astype(np.float64).copy(), mocap, STEPS_PER_ACTION, bid, GEOFENCE, cores)
+        return time.perf_counter() - t0
+
+    N = q0.shape[0]
+    n_cal = min(N, 8 * cores)
+    per_env_step = run(n_cal, 1) / n_cal                  # seconds of wall time per env-step at this thread count
+    budget = 12.0
+    n = int(min(N, max(n_cal, budget / max(per_env_step, 1e-9))))
+    reps = int(max(1, min(8, budget / max(per_env_step * n, 1e-9))))
+    dt = run(n, reps)
     return dict(value=n * reps / dt, unit="env-steps/s", cores=cores, kind="port",
-                sample=f"{n} envs x {reps} env-steps x {STEPS_PER_ACTION} substeps of the same workload, "
+                sample=f"first {n} envs x {reps} env-steps x {STEPS_PER_ACTION} substeps of the same workload ({dt:.1f} s), "
                        f"oracle/hsr_oracle.c fp64 with OpenMP over envs ({cores} threads); stand-in for CPU mujoco-py, "
                        "which is not installable here")
 
@@ -155,6 +172,12 @@ def main():
 
     for k in range(W):
         env_step(k)
+        substeps_done += d_ns.sum()     # same ops as the timed loop (torch loads its reduction kernels on first use)
+        dones += d_done.sum()
+    if W == 0:
+        substeps_done += d_ns.sum(); dones += d_done.sum()
+    barrier()
+    substeps_done.zero_(); dones.zero_()
     barrier()
     t0 = time.perf_counter()
     for k in range(W, W + K):
@@ -219,8 +242,7 @@ def main():
                      "note": "state stays L2/MALL-resident; the path is FP32-VALU/latency bound, not HBM bound (SURVEY.md 8d)"},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-        out["cpu_baseline"] = cpu_baseline(m, q0, goal, ctrl_host, cores)
+        out["cpu_baseline"] = cpu_baseline(m, q0, goal, ctrl_host, host_cores())
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0:

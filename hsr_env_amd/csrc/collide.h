@@ -31,23 +31,23 @@ struct KinGlobal {
     __device__ __forceinline__ v3 dof_axis(int k) const { return ld3(m.dof_axis, k); }
     __device__ __forceinline__ v3 dof_pos(int k) const { return ld3(m.dof_pos, k); }
 };
+__device__ __forceinline__ v3 sel3(bool c, v3 a, v3 b) { return mk3(c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z); }
 struct KinLane {          // constants of ONE link (the lane's) and of its first three scalar dofs
     int dofadr, dofnum, free_, qposadr, parent;
     v3 lpos, com;
     m3 lmat;
     float mass, inertia[6];
-    int dqadr[3], dtype[3];
-    v3 daxis[3], dpos[3];
+    int dqadr0, dqadr1, dqadr2, dtype0, dtype1, dtype2;       // named members, not arrays: a dynamically indexed array would live in scratch
+    v3 daxis0, daxis1, daxis2, dpos0, dpos1, dpos2;
     __device__ __forceinline__ void load(const DevModel &m, int l) {
         dofadr = m.link_dofadr[l]; dofnum = m.link_dofnum[l]; free_ = m.link_free[l]; qposadr = m.link_qposadr[l]; parent = m.link_parent[l];
         lpos = ld3(m.link_pos, l); lmat = ldm(m.link_mat, l); com = ld3(m.link_com, l); mass = m.link_mass[l];
 #pragma unroll
         for (int i = 0; i < 6; i++) inertia[i] = m.link_inertia[6 * l + i];
-#pragma unroll
-        for (int j = 0; j < 3; j++) {
-            const int k = dofadr + (j < dofnum ? j : 0);
-            dqadr[j] = m.dof_qposadr[k]; dtype[j] = m.dof_type[k]; daxis[j] = ld3(m.dof_axis, k); dpos[j] = ld3(m.dof_pos, k);
-        }
+        const int k0 = dofadr, k1 = dofadr + (1 < dofnum ? 1 : 0), k2 = dofadr + (2 < dofnum ? 2 : 0);
+        dqadr0 = m.dof_qposadr[k0]; dtype0 = m.dof_type[k0]; daxis0 = ld3(m.dof_axis, k0); dpos0 = ld3(m.dof_pos, k0);
+        dqadr1 = m.dof_qposadr[k1]; dtype1 = m.dof_type[k1]; daxis1 = ld3(m.dof_axis, k1); dpos1 = ld3(m.dof_pos, k1);
+        dqadr2 = m.dof_qposadr[k2]; dtype2 = m.dof_type[k2]; daxis2 = ld3(m.dof_axis, k2); dpos2 = ld3(m.dof_pos, k2);
     }
     __device__ __forceinline__ int link_dofadr(int) const { return dofadr; }
     __device__ __forceinline__ int link_dofnum(int) const { return dofnum; }
@@ -61,11 +61,50 @@ struct KinLane {          // constants of ONE link (the lane's) and of its first
     __device__ __forceinline__ void link_inertia(int, float *o) const {
 #pragma unroll
         for (int i = 0; i < 6; i++) o[i] = inertia[i]; }
-    __device__ __forceinline__ int dof_qposadr(int k) const { const int j = k - dofadr; return j == 0 ? dqadr[0] : (j == 1 ? dqadr[1] : dqadr[2]); }
-    __device__ __forceinline__ int dof_type(int k) const { const int j = k - dofadr; return j == 0 ? dtype[0] : (j == 1 ? dtype[1] : dtype[2]); }
-    __device__ __forceinline__ v3 dof_axis(int k) const { const int j = k - dofadr; return j == 0 ? daxis[0] : (j == 1 ? daxis[1] : daxis[2]); }
-    __device__ __forceinline__ v3 dof_pos(int k) const { const int j = k - dofadr; return j == 0 ? dpos[0] : (j == 1 ? dpos[1] : dpos[2]); }
+    __device__ __forceinline__ int dof_qposadr(int k) const { const int j = k - dofadr; return j == 0 ? dqadr0 : (j == 1 ? dqadr1 : dqadr2); }
+    __device__ __forceinline__ int dof_type(int k) const { const int j = k - dofadr; return j == 0 ? dtype0 : (j == 1 ? dtype1 : dtype2); }
+    __device__ __forceinline__ v3 dof_axis(int k) const { const int j = k - dofadr; return sel3(j == 0, daxis0, sel3(j == 1, daxis1, daxis2)); }
+    __device__ __forceinline__ v3 dof_pos(int k) const { const int j = k - dofadr; return sel3(j == 0, dpos0, sel3(j == 1, dpos1, dpos2)); }
 };
+
+// the same constants as KinLane, read on demand from a 52-float LDS record of the link (built once per launch with
+// KinLane::store): nothing stays in registers between tree levels
+struct KinLds {
+    const float *p;
+    __device__ __forceinline__ int link_dofadr(int) const { return (int)p[0]; }
+    __device__ __forceinline__ int link_dofnum(int) const { return (int)p[1]; }
+    __device__ __forceinline__ int link_free(int) const { return (int)p[2]; }
+    __device__ __forceinline__ int link_qposadr(int) const { return (int)p[3]; }
+    __device__ __forceinline__ int link_parent(int) const { return (int)p[4]; }
+    __device__ __forceinline__ v3 link_pos(int) const { return mk3(p[5], p[6], p[7]); }
+    __device__ __forceinline__ m3 link_mat(int) const { m3 r;
+#pragma unroll
+        for (int i = 0; i < 9; i++) r.a[i] = p[8 + i];
+        return r; }
+    __device__ __forceinline__ v3 link_com(int) const { return mk3(p[17], p[18], p[19]); }
+    __device__ __forceinline__ float link_mass(int) const { return p[20]; }
+    __device__ __forceinline__ void link_inertia(int, float *o) const {
+#pragma unroll
+        for (int i = 0; i < 6; i++) o[i] = p[21 + i]; }
+    __device__ __forceinline__ int dof_qposadr(int k) const { return (int)p[27 + k - (int)p[0]]; }
+    __device__ __forceinline__ int dof_type(int k) const { return (int)p[30 + k - (int)p[0]]; }
+    __device__ __forceinline__ v3 dof_axis(int k) const { const float *q = p + 33 + 3 * (k - (int)p[0]); return mk3(q[0], q[1], q[2]); }
+    __device__ __forceinline__ v3 dof_pos(int k) const { const float *q = p + 42 + 3 * (k - (int)p[0]); return mk3(q[0], q[1], q[2]); }
+};
+enum { KINLDS_FLOATS = 52 };
+__device__ __forceinline__ void kinlds_store(const KinLane &K, float *o) {
+    o[0] = (float)K.dofadr; o[1] = (float)K.dofnum; o[2] = (float)K.free_; o[3] = (float)K.qposadr; o[4] = (float)K.parent;
+    o[5] = K.lpos.x; o[6] = K.lpos.y; o[7] = K.lpos.z;
+#pragma unroll
+    for (int i = 0; i < 9; i++) o[8 + i] = K.lmat.a[i];
+    o[17] = K.com.x; o[18] = K.com.y; o[19] = K.com.z; o[20] = K.mass;
+#pragma unroll
+    for (int i = 0; i < 6; i++) o[21 + i] = K.inertia[i];
+    o[27] = (float)K.dqadr0; o[28] = (float)K.dqadr1; o[29] = (float)K.dqadr2; o[30] = (float)K.dtype0; o[31] = (float)K.dtype1; o[32] = (float)K.dtype2;
+    o[33] = K.daxis0.x; o[34] = K.daxis0.y; o[35] = K.daxis0.z; o[36] = K.daxis1.x; o[37] = K.daxis1.y; o[38] = K.daxis1.z; o[39] = K.daxis2.x; o[40] = K.daxis2.y; o[41] = K.daxis2.z;
+    o[42] = K.dpos0.x; o[43] = K.dpos0.y; o[44] = K.dpos0.z; o[45] = K.dpos1.x; o[46] = K.dpos1.y; o[47] = K.dpos1.z; o[48] = K.dpos2.x; o[49] = K.dpos2.y; o[50] = K.dpos2.z;
+    o[51] = 0.f;
+}
 
 // pose of link l from its (already computed) parent and its joint coordinates; also the world axes of its dofs
 template <class KC>
@@ -399,7 +438,7 @@ __device__ __forceinline__ int clip_poly(float *poly, int pstride, int poff, int
 
 // polygon scratch addressing: element (buf, vertex, xyz) lives at poly[((buf*8+vertex)*3+xyz)*pstride + poff]
 // (k_narrow: lane-interleaved pstride 64, poff lane; persistent kernel: private 48-float slot, pstride 1, poff 0)
-__device__ void collide_box_box_p(const Geom &G1, const Geom &G2, ContactOut &out, float *poly, int pstride, int poff) {
+__device__ __forceinline__ void collide_box_box_p(const Geom &G1, const Geom &G2, ContactOut &out, float *poly, int pstride, int poff) {
     v3 A[3], B[3];
     float s1[3] = {G1.size.x, G1.size.y, G1.size.z}, s2[3] = {G2.size.x, G2.size.y, G2.size.z};
 #pragma unroll
@@ -561,7 +600,6 @@ __device__ __forceinline__ v3 portal_dir(const Sup &p1, const Sup &p2, const Sup
 }
 // branch-free selects keep the portal in registers (struct assignment under divergent ifs made the compiler
 // place the three portal points in a scratch array with dynamic indexing: every MPR step went through memory)
-__device__ __forceinline__ v3 sel3(bool c, v3 a, v3 b) { return mk3(c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z); }
 __device__ __forceinline__ Sup selS(bool c, const Sup &a, const Sup &b) {
     Sup r;
     r.v = sel3(c, a.v, b.v); r.v1 = sel3(c, a.v1, b.v1); r.v2 = sel3(c, a.v2, b.v2);

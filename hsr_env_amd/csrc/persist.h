@@ -15,19 +15,20 @@
 #include "solve_mf.h"
 
 template <int G> struct PersistLayout {
-    int R, MS, oRows, oCnt, oB, envf, oPoly, total;
+    int R, MS, oRows, oCnt, oB, envf, oPoly, oKin, total;
     __host__ __device__ PersistLayout(int rows, int kstride, int npair_pad, int nlink, int ngeom) {
         R = rows; MS = G + 1;
         int a = 6 * R > kstride ? 6 * R : kstride;                            // row scalars / kin record
         oRows = 0; oCnt = (a + 3) & ~3;                                       // pair counts survive phases A-D next to the kin record
-        a = oCnt + npair_pad;
+        a = oCnt + (npair_pad + 3) / 4;                                        // one byte per pair
         int b = G * MS > C2_SIZE * G ? G * MS : C2_SIZE * G;                  // inertia matrix / contact records ...
         const int kin_tmp = 24 * nlink + 2 * G + 16 * ngeom;                   // ... or link poses + recursion scratch + qpos/qvel staging + geom placements
         if (kin_tmp > b) b = kin_tmp;
         oB = (a + 3) & ~3;
         envf = (oB + b + 3) & ~3;
         oPoly = envf * (64 / G);                                               // box-box polygon scratch: 4 slots of 48 floats per wave
-        total = oPoly + 4 * 48;
+        oKin = oPoly + 4 * 48;                                                 // per-link kinematic constants (KinLds), shared by the envs of the workgroup
+        total = oKin + KINLDS_FLOATS * nlink;
     }
 };
 
@@ -50,7 +51,7 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(DevModel m, DevState s, i
     float *E = lds + (size_t)g * L.envf;                                                                                     \
     float *rD = E + L.oRows, *rAref = rD + R, *rJar = rAref + R, *rJv = rJar + R, *rGr = rJv + R, *rDw = rGr + R;            \
     float *kAng = E + L.oRows, *kLin = kAng + 3 * nv, *kAnc = kAng + 6 * nv, *lk = kAng + 9 * nv;                            \
-    int *pcnt = reinterpret_cast<int *>(E + L.oCnt);                                                                         \
+    unsigned char *pcnt = reinterpret_cast<unsigned char *>(E + L.oCnt);                                                                       \
     float *M = E + L.oB, *con = E + L.oB;                                                                                    \
     /* kinematics scratch inside region B (dead before the solver writes M there) */                                        \
     float *xposL = E + L.oB, *xmatL = xposL + 3 * m.nlink, *recL = xmatL + 9 * m.nlink, *qposL = recL + 12 * m.nlink, *qvelL = qposL + G; \
@@ -66,6 +67,7 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(DevModel m, DevState s, i
     __shared__ float sMass[NLMAX];
     if (tid0 < nv) sParent[tid0] = m.dof_parent[tid0];
     if (tid0 < m.nlink && tid0 < NLMAX) { sMask[tid0] = m.link_dofmask[tid0]; sMass[tid0] = m.link_mass[tid0]; sDepth[tid0] = m.link_depth[tid0]; }
+    if (tid0 < m.nlink) { KinLane K0; K0.load(m, tid0); kinlds_store(K0, lds + L.oKin + KINLDS_FLOATS * tid0); }
 
     // ---------------- load the env state once; it lives in registers for the whole env-step
     float qpos_c = 0, qvel_c = 0, warm_c = 0;          // qpos_c: lane = qpos index; qvel_c / warm_c: lane = dof
@@ -101,8 +103,7 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(DevModel m, DevState s, i
             const View vq{qposL, 1}, vv{qvelL, 1}, vx{xposL, 1}, vm{xmatL, 1}, va{kAng, 1}, vl{kLin, 1}, vn{kAnc, 1}, vd{lk, 1};
             const View w0{recL, 1}, w1{recL + 3 * m.nlink, 1}, w2{recL + 6 * m.nlink, 1}, w3{recL + 9 * m.nlink, 1};
             const int mydepth = (c < m.nlink && c < NLMAX) ? sDepth[c] : -1;
-            KinLane K;
-            K.load(m, mydepth > 0 ? c : 0);        // this lane's link constants: independent loads, one round trip
+            const KinLds K{lds + L.oKin + KINLDS_FLOATS * (mydepth > 0 ? c : 0)};   // this lane's link constants, read from LDS where they are used
             if (valid && c == 0) kin_link0(vx, vm, vd, w0, w1, w2, w3);
             __syncthreads();
             for (int dlev = 1; dlev <= m.maxdepth; dlev++) {
@@ -138,7 +139,7 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(DevModel m, DevState s, i
             float *gw = qvelL + G;
             const int oGw = (int)(gw - E);
             if (valid) for (int gi = c; gi < m.ngeom; gi += G) geom_place(m.geom_rec + 32 * gi, View{xposL, 1}, View{xmatL, 1}, gw + 16 * gi);
-            for (int p0 = 0; p0 < m.npair_pad; p0 += G) { const int p = p0 + c; if (p < m.npair_pad) pcnt[p] = 0; }
+            for (int p0 = 0; p0 < m.npair_pad / 4; p0 += G) { const int p = p0 + c; if (p < m.npair_pad / 4) reinterpret_cast<int *>(pcnt)[p] = 0; }
             __syncthreads();
             const float4 *pg4 = reinterpret_cast<const float4 *>(m.pair_geo);
             int ncand = 0, nitems = 0;                             // wave-uniform
@@ -186,20 +187,27 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(DevModel m, DevState s, i
             if (nitems > 64) nitems = 64;
             __syncthreads();
             {
+                // every section rebuilds the geoms it needs from the placement cache, so that nothing but the item id
+                // stays live across the register-hungry narrowphases
                 const bool act = tid < nitems;
                 const int it = act ? sItems[tid] : 0;
-                const int ig = it >> 14, p = it & 0x3fff;
-                float *Ei = lds + (size_t)ig * L.envf;
-                const int ei = blockIdx.x * EPB + ig;
-                const float4 pa = pg4[2 * p], pb = pg4[2 * p + 1];
-                ContactOut out;
-                out.con = s.con + (size_t)ei * m.nslot * 8; out.slot = (int)pb.y; out.maxcnt = (int)pb.z; out.cnt = 0;
-                const int fn = act ? (int)pb.x : -1;
-                Geom G1, G2;
-                if (act) { G1 = geom_cached(Ei + oGw + 16 * (int)pa.x, m.geom_rec + 32 * (int)pa.x, m.mesh_vert4); G2 = geom_cached(Ei + oGw + 16 * (int)pa.y, m.geom_rec + 32 * (int)pa.y, m.mesh_vert4); }
+                const int fn = act ? (int)pg4[2 * (it & 0x3fff) + 1].x : -1;
+                auto item_geoms = [&](int item, Geom &A, Geom &B, ContactOut &o, unsigned char *&cntp) {
+                    const int ig = item >> 14, p = item & 0x3fff;
+                    float *Ei = lds + (size_t)ig * L.envf;
+                    const float4 pa = pg4[2 * p], pb = pg4[2 * p + 1];
+                    A = geom_cached(Ei + oGw + 16 * (int)pa.x, m.geom_rec + 32 * (int)pa.x, m.mesh_vert4);
+                    B = geom_cached(Ei + oGw + 16 * (int)pa.y, m.geom_rec + 32 * (int)pa.y, m.mesh_vert4);
+                    o.con = s.con + (size_t)(blockIdx.x * EPB + ig) * m.nslot * 8; o.slot = (int)pb.y; o.maxcnt = (int)pb.z; o.cnt = 0;
+                    cntp = reinterpret_cast<unsigned char *>(Ei + L.oCnt) + p;
+                };
                 PHASE(20);
-                if (fn == FN_PLANE_BOX) collide_plane_box(G1, G2, out);
-                else if (fn == FN_PLANE_CONVEX) collide_plane_convex(G1, G2, out);
+                if (fn == FN_PLANE_BOX || fn == FN_PLANE_CONVEX) {
+                    Geom G1, G2; ContactOut out; unsigned char *cntp;
+                    item_geoms(it, G1, G2, out, cntp);
+                    if (fn == FN_PLANE_BOX) collide_plane_box(G1, G2, out); else collide_plane_convex(G1, G2, out);
+                    *cntp = (unsigned char)out.cnt;
+                }
                 PHASE(21);
                 // convex pairs (MPR): one work item per MW-lane sub-group, the lanes share the hull scans of the support function
                 {
@@ -212,34 +220,23 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(DevModel m, DevState s, i
                     for (int r0 = 0; r0 < ncv; r0 += 64 / MW) {
                         const int k = r0 + tid / MW;
                         if (k < ncv) {
-                            const int src = sMpr[k];
-                            const int it2 = sItems[src];
-                            const int ig2 = it2 >> 14, p2 = it2 & 0x3fff;
-                            float *E2 = lds + (size_t)ig2 * L.envf;
-                            const int e2 = blockIdx.x * EPB + ig2;
-                            const float4 qa = pg4[2 * p2], qb = pg4[2 * p2 + 1];
-                            const Geom H1 = geom_cached(E2 + oGw + 16 * (int)qa.x, m.geom_rec + 32 * (int)qa.x, m.mesh_vert4);
-                            const Geom H2 = geom_cached(E2 + oGw + 16 * (int)qa.y, m.geom_rec + 32 * (int)qa.y, m.mesh_vert4);
-                            float *sx = s.sepax + (size_t)(3 * p2) * N + e2;
+                            const int it2 = sItems[sMpr[k]];
+                            Geom H1, H2; ContactOut o2; unsigned char *cntp;
+                            item_geoms(it2, H1, H2, o2, cntp);
+                            float *sx = s.sepax + (size_t)(3 * (it2 & 0x3fff)) * N + (blockIdx.x * EPB + (it2 >> 14));
                             const v3 d = mk3(sx[0], sx[N], sx[2 * (size_t)N]);
                             bool still = false;
                             if (d.x != 0.f || d.y != 0.f || d.z != 0.f) still = dot(support<MW>(H1, d) - support<MW>(H2, -d), d) < -1e-7f;
-                            int cnt2 = 0;
                             if (!still) {
                                 float depth; v3 dir, pos, sep;
                                 int nsup = 0;
                                 const bool hit = mpr_penetration<MW>(H1, H2, m.mpr_tolerance, m.mpr_iterations, depth, dir, pos, sep, nsup);
                                 if ((tid & (MW - 1)) == 0) {
-                                    if (hit) {
-                                        ContactOut o2;
-                                        o2.con = s.con + (size_t)e2 * m.nslot * 8; o2.slot = (int)qb.y; o2.maxcnt = (int)qb.z; o2.cnt = 0;
-                                        o2.add(pos, dir, -depth); sep = mk3(0, 0, 0);
-                                        cnt2 = o2.cnt;
-                                    }
+                                    if (hit) { o2.add(pos, dir, -depth); sep = mk3(0, 0, 0); }
                                     sx[0] = sep.x; sx[N] = sep.y; sx[2 * (size_t)N] = sep.z;
                                 }
                             }
-                            if ((tid & (MW - 1)) == 0) reinterpret_cast<int *>(E2 + L.oCnt)[p2] = cnt2;
+                            if ((tid & (MW - 1)) == 0) *cntp = (unsigned char)o2.cnt;
                         }
                     }
                 }
@@ -251,14 +248,18 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(DevModel m, DevState s, i
                     while (pend) {
                         const int rank = __popcll(pend & ((1ull << tid) - 1ull));
                         const bool mine = bb && ((pend >> tid) & 1ull) && rank < 4;
-                        if (mine) collide_box_box_slot(G1, G2, out, poly + 48 * rank);
+                        if (mine) {
+                            Geom G1, G2; ContactOut out; unsigned char *cntp;
+                            item_geoms(it, G1, G2, out, cntp);
+                            collide_box_box_slot(G1, G2, out, poly + 48 * rank);
+                            *cntp = (unsigned char)out.cnt;
+                        }
                         unsigned long long t = pend; int k = 0;
                         while (t && k < 4) { t &= t - 1; k++; }
                         pend = t;
                     }
                 }
                 PHASE(23);
-                if (act && fn != FN_CONVEX) reinterpret_cast<int *>(Ei + L.oCnt)[p] = out.cnt;
             }
         }
         __threadfence_block();       // contact records written to global by other lanes of this workgroup

@@ -106,6 +106,12 @@ int hsr_batch_set_graph(hsr_batch *b, int on);
 int hsr_batch_set_persistent(hsr_batch *b, int on);
 int hsr_batch_is_persistent(const hsr_batch *b);
 
+/* diagnostics (meaningful only in the -DHSR_PHASE_TIMING build, libhsrsim_timing.so; tools/phase_timing.py,
+ * tools/block_times.py): per-phase cycle sums of the last launches, and per-workgroup
+ * {start, end (s_memrealtime), HW_ID, XCC_ID, Newton trips, sphere-cull candidates, work items, rows} */
+int hsr_batch_phase_cycles(hsr_batch *b, unsigned long long *out /*[32]*/);
+int hsr_batch_block_times(hsr_batch *b, unsigned long long *out /*[nblocks,8]*/, int nblocks);
+
 #ifdef __cplusplus
 }
 #endif

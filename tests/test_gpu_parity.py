@@ -228,3 +228,39 @@ def test_full_size_invariants(models):
     obs2 = sim2.step(ctrl[:256], 300, m.body_id("block0"), 0.05)[0]
     assert np.array_equal(obs2, obs[:256])
     sim.close(); sim2.close()
+
+
+@pytest.mark.parametrize("cfg", ["cfg2", "cfg3", "cfg4"])
+def test_persistent_kernel_matches_per_substep_kernels(models, cfg):
+    """The whole-env-step persistent kernel (k_env_step_mf) and the per-substep kernel chain (k_kinematics, k_cull,
+    k_narrow, k_solve_mf) restate the same substep; they share the solver body and the narrowphase routines but not the
+    kinematics / cull code, so results are close but not bit-identical and contact-rich envs amplify the difference.
+    fp32 tolerance after 60 substeps: |dqpos| < 2e-5, |dqvel| < 2e-3 for >= 95 % of envs (median |dqpos| < 1e-6), and
+    the goal latch (done, nsteps) agrees wherever the states agree."""
+    m = models[cfg]
+    n = 256
+    rng = np.random.default_rng(21)
+    q, v, ctrl = random_states(m, n, rng)
+    goal = np.column_stack([rng.uniform(-0.1, 0.1, n), rng.uniform(-0.2, 0.2, n), np.full(n, 0.422)])
+    res = []
+    for persistent in (True, False):
+        sim = hs.BatchSim(m, n)
+        if persistent and not sim.is_persistent():
+            sim.close()
+            pytest.skip("model does not fit the persistent kernel")
+        sim.set_persistent(persistent)
+        assert sim.is_persistent() == persistent
+        sim.reset(qpos0=q, mocap=goal)
+        obs, rew, done, ns = sim.step(ctrl, 60, m.body_id("block0"), 0.02)
+        res.append((obs.copy(), done.copy(), ns.copy()))
+        assert not sim.bad_state()[1]
+        sim.close()
+    (oa, da, na), (ob, db, nb) = res
+    same_len = na == nb
+    assert same_len.mean() >= 0.98
+    dq = np.abs(oa[:, :m.nq] - ob[:, :m.nq]).max(axis=1)
+    dv = np.abs(oa[:, m.nq:] - ob[:, m.nq:]).max(axis=1)
+    ok = (dq < 2e-5) & (dv < 2e-3)
+    assert ok[same_len].mean() >= 0.95, (np.sort(dq)[-5:], np.sort(dv)[-5:])
+    assert np.median(dq) < 1e-6
+    assert (da == db)[same_len & ok].all()
