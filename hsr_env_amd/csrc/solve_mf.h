@@ -10,9 +10,13 @@
 #pragma once
 #include "solve_g.h"
 
-enum { C2_POS = 0, C2_N = 3, C2_T1 = 6, C2_T2 = 9, C2_L1 = 12, C2_L2 = 13, C2_ADR = 14, C2_DIM = 15, C2_MU = 16, C2_F0 = 17,
-       C2_F2 = 18, C2_F3 = 19, C2_ZONE = 20, C2_DM = 21, C2_K3 = 22, C2_B = 23, C2_KD = 24, C2_FW = 25, C2_TW = 28, C2_GN = 31,
-       C2_U = 37, C2_PAIR = 43, C2_SLOT = 44, C2_SIZE = 45 };
+// contact record in LDS: 11 float4 (16-B aligned), grouped so that each consumer needs few ds_read_b128:
+//   q0 pos.xyz L1 | q1 n.xyz L2 | q2 t1.xyz ADR | q3 t2.xyz DIM | q4 MU F0 F2 F3 | q5 ZONE DM K3 B | q6 fw.xyz KD | q7 tw.xyz - |
+//   q8..q10 GN[6] U[6].   PAIR / SLOT (written by E2, consumed at the top of E3) alias q7.
+enum { C2_POS = 0, C2_L1 = 3, C2_N = 4, C2_L2 = 7, C2_T1 = 8, C2_ADR = 11, C2_T2 = 12, C2_DIM = 15, C2_MU = 16, C2_F0 = 17,
+       C2_F2 = 18, C2_F3 = 19, C2_ZONE = 20, C2_DM = 21, C2_K3 = 22, C2_B = 23, C2_FW = 24, C2_KD = 27, C2_TW = 28, C2_SLOT = 30, C2_PAIR = 31,
+       C2_GN = 32, C2_U = 38, C2_SIZE = 44, C2_AX = 4, C2_AXS = 4 };
+__device__ __forceinline__ float4 lds4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 
 template <int G> struct MfLayout {
     int R, MS, oRows, oB, total;
