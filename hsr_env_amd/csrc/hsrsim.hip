@@ -177,6 +177,13 @@ struct hsr_batch {
     std::vector<hipEvent_t> kev;
 };
 
+// the persistent kernel instantiations: (lanes per env, compile-time bound on nv)
+typedef void (*persist_fn)(DevModel, DevState, int, int, float);
+static persist_fn persist_kernel(int group, int nv) {
+    if (group == 16) return nv <= 8 ? k_env_step_mf<16, 8> : (nv <= 13 ? k_env_step_mf<16, 13> : k_env_step_mf<16, 16>);
+    return nv <= 25 ? k_env_step_mf<32, 25> : k_env_step_mf<32, 32>;
+}
+
 template <typename T>
 static int dalloc(hsr_batch *b, T **p, size_t count) {
     void *q = nullptr;
@@ -496,8 +503,7 @@ extern "C" int hsr_batch_create(const hsr_model *m, int n_envs, int device_id, h
         }
         if (b->persist_lds_bytes > 160 * 1024) b->persist = false;
         else if (b->persist_lds_bytes > 48 * 1024) {
-            if (b->group == 16) HIPCHK(hipFuncSetAttribute((const void *)k_env_step_mf<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->persist_lds_bytes));
-            else HIPCHK(hipFuncSetAttribute((const void *)k_env_step_mf<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->persist_lds_bytes));
+            HIPCHK(hipFuncSetAttribute((const void *)persist_kernel(b->group, d.nv), hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->persist_lds_bytes));
         }
     }
     if (getenv("HSR_DEBUG")) {
@@ -510,9 +516,9 @@ extern "C" int hsr_batch_create(const hsr_model *m, int n_envs, int device_id, h
         fprintf(stderr, "[hsrsim] solver %d group %d: occupancy API says %d workgroups per CU\n", b->solver, b->group, nb);
         if (b->persist && b->group == 16) {
             int pb = -1;
-            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&pb, k_env_step_mf<16>, 64, b->persist_lds_bytes);
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&pb, persist_kernel(b->group, d.nv), 64, b->persist_lds_bytes);
             hipFuncAttributes fb;
-            if (hipFuncGetAttributes(&fb, (const void *)k_env_step_mf<16>) == hipSuccess)
+            if (hipFuncGetAttributes(&fb, (const void *)persist_kernel(b->group, d.nv)) == hipSuccess)
                 fprintf(stderr, "[hsrsim] k_env_step_mf<16>: regs %d, static LDS %zu, dyn LDS %zu, scratch %zu -> %d workgroups per CU\n", fb.numRegs, fb.sharedSizeBytes, b->persist_lds_bytes, fb.localSizeBytes, pb);
         }
     }
@@ -675,8 +681,7 @@ extern "C" int hsr_batch_step_dev(hsr_batch *b, const float *d_ctrl, int n_subst
     if (b->persist && n_substeps > 0) {
         const int epb = 64 / b->group;
         if (b->profiling) { hipEvent_t ev; for (int k = 0; k < 3; k++) { hipEventCreate(&ev); hipEventRecord(ev, st); b->kev.push_back(ev); } }
-        if (b->group == 16) hipLaunchKernelGGL(k_env_step_mf<16>, dim3((N + epb - 1) / epb), dim3(64), b->persist_lds_bytes, st, b->dm, b->ds, n_substeps, goal_body, geofence);
-        else hipLaunchKernelGGL(k_env_step_mf<32>, dim3((N + epb - 1) / epb), dim3(64), b->persist_lds_bytes, st, b->dm, b->ds, n_substeps, goal_body, geofence);
+        hipLaunchKernelGGL(persist_kernel(b->group, b->dm.nv), dim3((N + epb - 1) / epb), dim3(64), b->persist_lds_bytes, st, b->dm, b->ds, n_substeps, goal_body, geofence);
         if (b->profiling) { hipEvent_t ev; hipEventCreate(&ev); hipEventRecord(ev, st); b->kev.push_back(ev); }   // slots 0,1 empty; slot 2 = the persistent kernel
     } else if (b->use_graph && !b->profiling && n_substeps > 0) {
         GraphKey key{n_substeps, goal_body, geofence};

@@ -32,10 +32,11 @@ template <int G> struct PersistLayout {
     }
 };
 
-template <int G>
+// NVT: compile-time bound on nv (nv <= NVT <= G); the matrix loops of the solver run to NVT instead of G
+template <int G, int NVT>
 __global__ void __launch_bounds__(64, 2) k_env_step_mf(DevModel m, DevState s, int n_substeps, int goal_body, float geofence) {
     extern __shared__ __align__(16) float lds[];
-    constexpr int EPB = 64 / G;
+    constexpr int EPB = 64 / G, NK = NVT;
     const PersistLayout<G> L(m.njmax, s.kstride, m.npair_pad, m.nlink, m.ngeom);
     const int tid0 = threadIdx.x;
     const int N = s.N, nv = m.nv, nq = m.nq, R = L.R, MS = L.MS;

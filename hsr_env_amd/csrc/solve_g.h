@@ -77,10 +77,10 @@ template <int G> __device__ __forceinline__ int glast(int v) {   // value of the
 // in-register cooperative Cholesky: lane c holds row c (entries k <= c) of an SPD matrix; on return row c of L in
 // row[0..c] (entries k > c are scratch) and invd = 1 / L[c][c].  Columns j >= ndense are known to have no
 // off-diagonal entries (block-diagonal tail of M): only their pivots are taken.
-template <int G> __device__ __forceinline__ bool chol_g(float (&row)[G], float &invd, int nv, int ndense, int c) {
+template <int G, int NK = G> __device__ __forceinline__ bool chol_g(float (&row)[G], float &invd, int nv, int ndense, int c) {
     bool ok = true;
     invd = 1.f;
-    static_for<0, G>([&](auto jc) {
+    static_for<0, NK>([&](auto jc) {
         constexpr int j = decltype(jc)::value;
         if (j < nv) {
             float ajj = gbcast<G, j>(row[j]);
@@ -90,7 +90,7 @@ template <int G> __device__ __forceinline__ bool chol_g(float (&row)[G], float &
             if (c == j) invd = inv;
             row[j] = lcj;
             if (j < ndense) {
-                static_for<j + 1, G>([&](auto ic) {
+                static_for<j + 1, NK>([&](auto ic) {
                     constexpr int i = decltype(ic)::value;
                     row[i] -= lcj * gbcast<G, i>(lcj);               // unconditional: entries i > c are never read
                 });

@@ -30,12 +30,12 @@ template <int G> struct MfLayout {
 };
 
 // tile-free triangular solves: lane c holds lo[k] = L[c][k] (k < c, else 0) and invd = 1 / L[c][c]
-template <int G> __device__ __forceinline__ float chol_solve_mf(const float (&row)[G], float invd, float b, int nv, int c) {
+template <int G, int NK = G> __device__ __forceinline__ float chol_solve_mf(const float (&row)[G], float invd, float b, int nv, int c) {
     float lo[G];
 #pragma unroll
-    for (int k = 0; k < G; k++) lo[k] = (k < c) ? row[k] : 0.f;
+    for (int k = 0; k < NK; k++) lo[k] = (k < c) ? row[k] : 0.f;
     float sacc = b, y = 0.f;
-    static_for<0, G>([&](auto jc) {
+    static_for<0, NK>([&](auto jc) {
         constexpr int j = decltype(jc)::value;
         if (j < nv) {
             const float yj = gbcast<G, j>(sacc * invd);
@@ -45,8 +45,8 @@ template <int G> __device__ __forceinline__ float chol_solve_mf(const float (&ro
     });
     // L^T x = y: x_j = (y_j - sum_{i > j} L[i][j] x_i) / L[j][j]; the sum runs over lanes (lo[j] is 0 for lanes i <= j)
     float x = 0.f;
-    static_for<0, G>([&](auto jc) {
-        constexpr int j = G - 1 - decltype(jc)::value;
+    static_for<0, NK>([&](auto jc) {
+        constexpr int j = NK - 1 - decltype(jc)::value;
         if (j < nv) {
             const float tot = gsum<G>(lo[j] * x);
             if (c == j) x = (y - tot) * invd;
@@ -58,7 +58,7 @@ template <int G> __device__ __forceinline__ float chol_solve_mf(const float (&ro
 template <int G>
 __global__ void __launch_bounds__(64, 2) k_solve_mf(DevModel m, DevState s, int mode, int goal_body, float geofence, int debug) {
     extern __shared__ __align__(16) float lds[];
-    constexpr int EPB = 64 / G;
+    constexpr int EPB = 64 / G, NK = G;
     const MfLayout<G> L(m.njmax, s.kstride);
     const int tid = threadIdx.x, g = tid / G, c = tid % G;
     const int e_raw = blockIdx.x * EPB + g;
