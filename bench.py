@@ -33,11 +33,10 @@ def sample_inputs(m, n, seed, offset):
     (x,y) ~ U([-.1,.1]x[-.2,.2]), z = .422, yaw ~ U(-pi,pi); goal ~ U(same box) but at least
     2*geofence from the block so that an early exit needs the robot to push the block there."""
     rng = np.random.Generator(np.random.Philox(key=[seed, offset]))
-    nrob = m.nu
     q = np.tile(m.qpos0, (n, 1))
-    nb = (m.nq - nrob) // 7
-    for b in range(nb):
-        a = nrob + 7 * b
+    blocks = m.free_joint_qadrs()
+    nb = len(blocks)
+    for b, a in enumerate(blocks):
         yaw = rng.uniform(-np.pi, np.pi, n)
         q[:, a] = rng.uniform(-0.1, 0.1, n)
         q[:, a + 1] = rng.uniform(-0.2, 0.2, n) if nb == 1 else rng.uniform(-0.04, 0.04, n) + 0.13 * (b - (nb - 1) / 2)
@@ -45,8 +44,9 @@ def sample_inputs(m, n, seed, offset):
         q[:, a + 3] = np.cos(yaw / 2); q[:, a + 4] = 0; q[:, a + 5] = 0; q[:, a + 6] = np.sin(yaw / 2)
     goal = np.column_stack([rng.uniform(-0.1, 0.1, n), rng.uniform(-0.2, 0.2, n), np.full(n, 0.422)])
     if nb:
+        a0 = blocks[0]
         for _ in range(50):
-            close = np.linalg.norm(goal[:, :2] - q[:, nrob:nrob + 2], axis=1) < 2 * GEOFENCE
+            close = np.linalg.norm(goal[:, :2] - q[:, a0:a0 + 2], axis=1) < 2 * GEOFENCE
             if not close.any():
                 break
             goal[close, 0] = rng.uniform(-0.1, 0.1, close.sum()); goal[close, 1] = rng.uniform(-0.2, 0.2, close.sum())
@@ -69,7 +69,7 @@ def cpu_baseline(m, q0, goal, ctrl, cores):
     """Oracle (fp64 C restatement, OpenMP over envs) on the host cores, bounded sample of the same workload:
     a calibration pass on 8 envs per thread sizes the sample (first n envs, r env-steps) to about 12 s."""
     from oracle import oracle as orc
-    bid = m.body_id("block0") if "block0" in m.names["body"] else -1
+    bid = m.body_id(m.block_body()) if m.block_body() else -1
 
     def run(n, reps):
         qpos = q0[:n].astype(np.float64).copy(); qvel = np.zeros((n, m.nv)); warm = np.zeros((n, m.nv))
@@ -102,6 +102,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-persistent", action="store_true", help="per-substep kernels instead of the persistent env-step kernel")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="control-flow rehearsal of the N>1 path on a box with one GPU: every rank uses cuda:0 and the all-gather "
+                         "goes through gloo on host copies (RCCL refuses two ranks on one device); the number it prints is not a result")
     args = ap.parse_args()
 
     import torch
@@ -114,11 +117,16 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    if args.rehearse_on_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if args.rehearse_on_one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     m = load_config(args.config)
     n = args.envs_per_gpu
@@ -149,7 +157,7 @@ def main():
     d_ns = torch.empty(n, dtype=torch.int32, device=dev)
     d_pack = torch.empty((n, nobs + 2), dtype=torch.float32, device=dev)
     d_all = torch.empty((world * n, nobs + 2), dtype=torch.float32, device=dev) if world > 1 else None
-    bid = m.body_id("block0") if "block0" in m.names["body"] else -1
+    bid = m.body_id(m.block_body()) if m.block_body() else -1
     substeps_done = torch.zeros((), dtype=torch.int64, device=dev)
     dones = torch.zeros((), dtype=torch.int64, device=dev)
 
@@ -163,7 +171,12 @@ def main():
         sim.reset_dev(None, d_rq[k].data_ptr(), d_rg[k].data_ptr())     # `if done: env.reset()`
         if world > 1:
             d_pack[:, :nobs] = d_obs; d_pack[:, nobs] = d_rew; d_pack[:, nobs + 1] = d_done
-            dist.all_gather_into_tensor(d_all, d_pack)
+            if args.rehearse_on_one_gpu:
+                h_all = torch.empty(d_all.shape, dtype=d_all.dtype)
+                dist.all_gather_into_tensor(h_all, d_pack.cpu())
+                d_all.copy_(h_all)
+            else:
+                dist.all_gather_into_tensor(d_all, d_pack)
 
     def barrier():
         if world > 1:
@@ -187,7 +200,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if args.rehearse_on_one_gpu else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 

@@ -374,6 +374,24 @@ class Model:
     def body_id(self, name: str) -> int:
         return self.names["body"].index(name)
 
+    def scalar_joints(self):
+        """(qpos addresses, dof addresses) of the 1-dof joints (the robot), in joint order; scenes differ in whether the
+        block's free joint comes before (cupboard-world.xml) or after (world.xml + util.py injection) the robot."""
+        qa = [a for (a, n) in self.meta["joint_qposadr"] if n == 1]
+        da = [d for (a, n), d in zip(self.meta["joint_qposadr"], self.meta["joint_dofadr"]) if n == 1]
+        return np.array(qa, dtype=int), np.array(da, dtype=int)
+
+    def free_joint_qadrs(self):
+        """qpos start address of every free joint (x y z qw qx qy qz), in joint order."""
+        return [a for (a, n) in self.meta["joint_qposadr"] if n == 7]
+
+    def block_body(self) -> str:
+        """Name of the first free body: `block0` (util.py:109) or `block` (cupboard-world.xml:113)."""
+        for cand in ("block0", "block"):
+            if cand in self.names["body"]:
+                return cand
+        return ""
+
     def joint_qpos_addr(self, name: str):
         """mujoco_py ``model.get_joint_qpos_addr`` (reference use: hsr/env.py:153)."""
         j = self.names["joint"].index(name)
@@ -887,6 +905,9 @@ CONFIGS = {
     "cfg2": dict(dofs=["slide_x", "slide_y"], n_blocks=1),
     "cfg3": dict(dofs=ALL_DOFS, n_blocks=1),
     "cfg4": dict(dofs=ALL_DOFS, n_blocks=3),
+    # the cupboard scene (cupboard-world.xml:91-116) with its own `block` / `blockjoint`, the shape of the
+    # hsr/__init__.py:10-19 demo; many more box geoms -> 274 candidate pairs
+    "cupboard": dict(dofs=ALL_DOFS, n_blocks=0, xml_file="models/cupboard-world.xml"),
 }
 MODEL_DIR = Path(__file__).parent / "models"
 

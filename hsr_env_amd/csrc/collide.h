@@ -844,10 +844,10 @@ __global__ void __launch_bounds__(64) k_cull(DevModel m, DevState s) {
 __global__ void __launch_bounds__(64) k_narrow(DevModel m, DevState s) {
     __shared__ float poly[2 * 8 * 3 * 64];
     __shared__ float4 vbuf[2][MAXMESHV];
-    __shared__ int sPre[256];
+    __shared__ int sPre[384];
     const int lane = threadIdx.x;
     const int N = s.N;
-    // inclusive prefix of 64-item chunks per pair (npair <= 256), every wave computes the same table
+    // inclusive prefix of 64-item chunks per pair (npair <= 384), every wave computes the same table
     int run = 0;
     for (int base = 0; base < m.npair; base += 64) {
         const int p = base + lane;

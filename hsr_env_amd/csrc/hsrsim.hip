@@ -337,7 +337,7 @@ extern "C" int hsr_batch_create(const hsr_model *m, int n_envs, int device_id, h
     const int *sz = m->sizes;
     d.nq = sz[HSR_NQ]; d.nv = sz[HSR_NV]; d.nu = sz[HSR_NU]; d.nlink = sz[HSR_NLINK]; d.nbody = sz[HSR_NBODY];
     d.ngeom = sz[HSR_NGEOM]; d.npair = sz[HSR_NPAIR]; d.nslot = sz[HSR_NSLOT]; d.nconmax = sz[HSR_NCONMAX]; d.njmax = sz[HSR_NJMAX];
-    if (d.npair > 256) return fail(HSR_EINVAL, "more than 256 candidate geom pairs");
+    if (d.npair > 384) return fail(HSR_EINVAL, "more than 384 candidate geom pairs");
     d.nM = d.nv * (d.nv + 1) / 2;
     d.ndense = sz[13];
     d.timestep = (float)m->opt[0]; d.impratio = (float)m->opt[1]; d.gravz = (float)m->opt[2]; d.tolerance = (float)m->opt[3];

@@ -267,7 +267,7 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(DevModel m, DevState s, i
         __syncthreads();
         PHASE(17);
         // ---------------- S: dynamics + constraint solve + Euler (shared body)
-        constexpr int MAXCH = 256 / G;
+        constexpr int MAXCH = 384 / G;          // pair-count chunks of G pairs (npair <= 384, checked at batch creation)
         int cnt_ch[MAXCH];
 #pragma unroll
         for (int ch = 0; ch < MAXCH; ch++) { const int p = ch * G + c; cnt_ch[ch] = (valid && p < m.npair) ? pcnt[p] : 0; }

@@ -222,7 +222,7 @@ __global__ void __launch_bounds__(64) k_solve_g(DevModel m, DevState s, int mode
     PHASE_T0();
     // ---------------- phase A: every first-level global load of the kernel is issued here, back to back, so that
     // their (fabric / Infinity-Cache) latencies overlap; the data was written by the previous kernels.
-    constexpr int MAXCH = 256 / G;                         // pair-count chunks of G pairs (npair <= 256)
+    constexpr int MAXCH = 384 / G;                         // pair-count chunks of G pairs (npair <= 384)
     int cnt_ch[MAXCH];
     {
         const int *cp = s.ncon_pair + (size_t)e * m.npair_pad;

@@ -79,7 +79,7 @@ __global__ void __launch_bounds__(64, 2) k_solve_mf(DevModel m, DevState s, int 
 
     PHASE_T0();
     // ---------------- phase A: all first-level global loads, back to back
-    constexpr int MAXCH = 256 / G;
+    constexpr int MAXCH = 384 / G;          // pair-count chunks of G pairs (npair <= 384, checked at batch creation)
     int cnt_ch[MAXCH];
     {
         const int *cp = s.ncon_pair + (size_t)e * m.npair_pad;

@@ -20,10 +20,9 @@ NENV, NSUB = 6, 80
 def inputs(m, seed):
     rng = np.random.default_rng(seed)
     q = np.tile(m.qpos0, (NENV, 1))
-    nrob = m.nu
-    nb = (m.nq - nrob) // 7
-    for b in range(nb):
-        a = nrob + 7 * b
+    blocks = m.free_joint_qadrs()
+    nb = len(blocks)
+    for b, a in enumerate(blocks):
         yaw = rng.uniform(-np.pi, np.pi, NENV)
         q[:, a] = rng.uniform(-0.1, 0.1, NENV)
         q[:, a + 1] = rng.uniform(-0.2, 0.2, NENV) if nb == 1 else rng.uniform(-0.04, 0.04, NENV) + 0.13 * (b - (nb - 1) / 2)
@@ -34,7 +33,7 @@ def inputs(m, seed):
 
 
 def main():
-    for cfg in ("cfg1", "cfg2", "cfg3", "cfg4"):
+    for cfg in ("cfg1", "cfg2", "cfg3", "cfg4", "cupboard"):
         m = load_config(cfg)
         q0, ctrl = inputs(m, 1234)
         traj_q = np.zeros((NENV, NSUB, m.nq)); traj_v = np.zeros((NENV, NSUB, m.nv)); ncon = np.zeros((NENV, NSUB), np.int32)

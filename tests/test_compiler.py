@@ -8,7 +8,8 @@ from hsr_env_amd import compiler as hc
 
 # cfg: nq nv nu obs nbody collidable-geoms candidate-pairs   
 TABLE = {"cfg1": (2, 2, 2, 4, 47, 17, 30), "cfg2": (9, 8, 2, 17, 48, 18, 47),
-         "cfg3": (14, 13, 7, 27, 48, 18, 114), "cfg4": (28, 25, 7, 53, 50, 20, 151)}
+         "cfg3": (14, 13, 7, 27, 48, 18, 114), "cfg4": (28, 25, 7, 53, 50, 20, 151),
+         "cupboard": (14, 13, 7, 27, 53, 28, 274)}
 
 
 @pytest.mark.parametrize("cfg", list(TABLE))
