@@ -94,7 +94,8 @@ class VecHSREnv:
         self.record_freq = record_freq or 20
         self.render_freq = render_freq or 20
         self.frame_skip = self.record_freq                              # hsr/env.py:68 passes record_freq
-        self._block_name = "block0"
+        # hsr/env.py:58 hard-codes 'block0' (the util.py:109 injection); cupboard-world.xml:113 names its body 'block'
+        self._block_name = model.block_body() or "block0"
         self._finger_names = ["hand_l_distal_link", "hand_r_distal_link"]
         if sim is None:
             from .sim import BatchSim

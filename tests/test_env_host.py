@@ -125,3 +125,22 @@ def test_math_helpers():
     c, s = np.cos(.3), np.sin(.3)
     assert np.allclose(mat2euler(np.array([[c, -s, 0], [s, c, 0], [0, 0, 1]])), [0, 0, .3])
     assert distance_between(np.zeros(3), np.array([3., 4, 0])) == 5
+
+
+def test_init_demo_shape_runs_on_the_cupboard_scene(models):
+    """hsr/__init__.py:10-27 verbatim in shape: GoalSpec(a='block', b=point, distance=.05), starts={'blockjoint': Box(7)},
+    random actions, reset when done - the body / joint names exist as such only in cupboard-world.xml:113-116."""
+    m = models["cupboard"]
+    starts = dict(blockjoint=Box(low=np.array([-.1, -.2, .418, 0, 0, -1, 0]), high=np.array([.1, +.2, .418, 1, 0, +1, 0])))
+    env = make_env(models, "cupboard", 2, goals=[GoalSpec(a="block", b=np.array([0, 0, .498]), distance=.05)], starts=starts,
+                   steps_per_action=10)
+    env.seed(0)
+    obs = env.reset()
+    a0, a1 = m.joint_qpos_addr("blockjoint")
+    assert (a0, a1) == (0, 7) and obs.shape == (2, 27)             # the block's free joint comes first in this scene
+    assert (np.abs(obs[:, 0]) <= .1).all() and (np.abs(obs[:, 1]) <= .2).all() and np.allclose(obs[:, 2], .418)
+    for _ in range(3):
+        action = np.stack([env.action_space.sample() for _ in range(2)])
+        s, r, t, i = env.step(action)
+        assert s.shape == (2, 27) and np.isfinite(s).all() and not t.any()
+    assert np.allclose(env.block_pos(), env.sim.body_xpos(m.body_id("block")))
