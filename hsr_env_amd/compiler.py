@@ -180,11 +180,33 @@ class _Body:
     inertial: Optional[dict] = None
 
 
+def _apply_setters(root, set_xml):
+    """hsr/util.py:129-135 (`for change in changes`): the path's last component is the attribute, the rest an ElementTree
+    path relative to the root of the file being mutated; a path that matches nothing in this file is skipped."""
+    import re
+    for path, value in set_xml:
+        parent = re.sub('/[^/]*$', '', str(path))
+        elt = root.find(parent)
+        if isinstance(elt, ET.Element):
+            elt.set(re.search('[^/]*$', str(path))[0], str(value))
+
+
 def _parse_tree(ref_root: Path, xml_file: str, dofs: Sequence[str], n_blocks: int,
-                block_pos: np.ndarray):
+                block_pos: np.ndarray, set_xml=()):
     xml_path = ref_root / xml_file
     root = ET.parse(xml_path).getroot()
     meta = {}
+    # -- block injection (util.py:106-127), then the --set-xml changes (util.py:129-135), file by file as mutate_tree does
+    worldbody = root.find("worldbody")
+    for i in range(n_blocks):
+        name = f"block{i}"
+        body = ET.SubElement(worldbody, "body",
+                             attrib=dict(name=name, pos=" ".join(repr(float(x)) for x in block_pos[i])))
+        ET.SubElement(body, "geom", attrib=dict(name=name, type="box", mass="1",
+                                                size=".05 .025 .017", condim="6",
+                                                solimp="0.99 0.99 0.01", solref="0.01 1"))
+        ET.SubElement(body, "freejoint", attrib=dict(name=f"block{i}joint"))
+    _apply_setters(root, set_xml)
 
     # -- options / compiler -------------------------------------------------------------
     opt = {"timestep": 0.002, "impratio": 1.0, "cone": "pyramidal"}
@@ -215,23 +237,13 @@ def _parse_tree(ref_root: Path, xml_file: str, dofs: Sequence[str], n_blocks: in
     meshes = {m.get("name"): meshdir / m.get("file") for m in root.find("asset").findall("mesh")}
 
     # -- splice <include> (util.py:148-151 keeps includes relative) -----------------------
-    worldbody = root.find("worldbody")
     for i, child in enumerate(list(worldbody)):
         if child.tag == "include":
             inc = ET.parse(xml_path.parent / child.get("file")).getroot()
+            _apply_setters(inc, set_xml)
             worldbody.remove(child)
             for j, b in enumerate(list(inc)):
                 worldbody.insert(i + j, b)
-
-    # -- block injection (util.py:106-127) --------------------------------------------------
-    for i in range(n_blocks):
-        name = f"block{i}"
-        body = ET.SubElement(worldbody, "body",
-                             attrib=dict(name=name, pos=" ".join(repr(float(x)) for x in block_pos[i])))
-        ET.SubElement(body, "geom", attrib=dict(name=name, type="box", mass="1",
-                                                size=".05 .025 .017", condim="6",
-                                                solimp="0.99 0.99 0.01", solref="0.01 1"))
-        ET.SubElement(body, "freejoint", attrib=dict(name=f"block{i}joint"))
 
     # -- DOF filter (util.py:137-146) ---------------------------------------------------------
     actuators = []
@@ -536,17 +548,20 @@ def mass_matrix(m: Model, qpos):
 # ----------------------------------------------------------------------------- compile
 def compile_model(dofs: Sequence[str] = ("slide_x", "slide_y"), n_blocks: int = 0,
                   block_pos: Optional[np.ndarray] = None, xml_file: str = "models/world.xml",
-                  ref_root: Path = DEFAULT_REF_ROOT) -> Model:
+                  ref_root: Path = DEFAULT_REF_ROOT, set_xml: Sequence = ()) -> Model:
     ref_root = Path(ref_root)
     if block_pos is None:
         # resting height on the pan: 0.405 + 0.017 (world.xml:83-84, util.py:120)
         block_pos = np.array([[0.0, 0.12 * (i - (n_blocks - 1) / 2.0), 0.422]
                               for i in range(n_blocks)]).reshape(n_blocks, 3)
     block_pos = np.asarray(block_pos, dtype=np.float64).reshape(n_blocks, 3)
-    parsed = _parse_tree(ref_root, xml_file, list(dofs), n_blocks, block_pos)
+    set_xml = [(str(p), str(v)) for p, v in set_xml]
+    parsed = _parse_tree(ref_root, xml_file, list(dofs), n_blocks, block_pos, set_xml)
     bodies: List[_Body] = parsed["bodies"]
     opt = parsed["opt"]
     meta = dict(parsed["meta"])
+    if set_xml:
+        meta.update(set_xml=[list(c) for c in set_xml])
     meta.update(dofs=list(dofs), n_blocks=n_blocks, xml_file=xml_file,
                 decisions="H1 malformed pos->0; H2 inertiafromgeom all geoms density 1000 (legacy "
                           "mesh inertia); H3 default class 'all' is global; H4 hinge ranges in "

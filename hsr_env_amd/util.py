@@ -5,6 +5,7 @@ configurations; any other combination is compiled on the fly when the reference'
 from __future__ import annotations
 
 import argparse
+from collections import namedtuple
 import re
 from pathlib import Path
 
@@ -45,7 +46,7 @@ def add_wrapper_args(parser):
     parser.add_argument('--block-space', type=parse_space(dim=4))
     parser.add_argument('--goal-space', type=parse_space(dim=3), required=True)
     parser.add_argument('--xml-file', type=Path, default='models/world.xml')
-    parser.add_argument('--set-xml', action='append')
+    parser.add_argument('--set-xml', type=xml_setter, action='append')
     parser.add_argument('--use-dof', type=str, action='append', default=[])
     parser.add_argument('--geofence', type=float, required=True)
     parser.add_argument('--n-blocks', type=int, default=0)
@@ -66,14 +67,24 @@ def hierarchical_parse_args(parser, argv=None):
     return out
 
 
-def model_for(dofs, n_blocks, xml_file='models/world.xml'):
+XMLSetter = namedtuple('XMLSetter', 'path value')          # hsr/util.py:84
+
+
+def xml_setter(arg: str):
+    """hsr/util.py:43-44: `--set-xml path,value`."""
+    return XMLSetter(*arg.split(','))
+
+
+def model_for(dofs, n_blocks, xml_file='models/world.xml', set_xml=()):
+    """The committed blob when the request is one of the compiled configs; otherwise the model compiler on the MJCF / STL
+    data files (present where the reference tree is; --set-xml always takes this route)."""
     dofs = [d for d in ALL_DOFS if d in dofs]
     for name, kw in CONFIGS.items():
-        if kw['dofs'] == dofs and kw['n_blocks'] == n_blocks and str(xml_file) == 'models/world.xml':
+        if not set_xml and kw['dofs'] == dofs and kw['n_blocks'] == n_blocks and str(xml_file) == kw.get('xml_file', 'models/world.xml'):
             return load_config(name)
     if not DEFAULT_REF_ROOT.exists():
         raise IOError(f"no compiled model for dofs={dofs} n_blocks={n_blocks} and the MJCF/STL data files are not on disk")
-    return compile_model(dofs=dofs, n_blocks=n_blocks, xml_file=str(xml_file))
+    return compile_model(dofs=dofs, n_blocks=n_blocks, xml_file=str(xml_file), set_xml=list(set_xml))
 
 
 def env_wrapper(func):
@@ -81,12 +92,11 @@ def env_wrapper(func):
     GoalSpec(a=block_space, b=goal_space) which cannot run (SURVEY.md 8a defects); the build uses the
     working shape GoalSpec('block0', goal_space, geofence) and block_space as the blocks' reset pose."""
     def _wrapper(set_xml, use_dof, n_blocks, goal_space, xml_file, geofence, env_args, block_space, **kwargs):
-        if set_xml:
-            raise NotImplementedError('--set-xml needs the model compiler with the MJCF on disk (SURVEY.md 8f rank 2)')
-        model = model_for(use_dof, n_blocks, xml_file)
-        goals = [GoalSpec(a='block0', b=goal_space, distance=geofence)] if n_blocks > 0 else None
+        model = model_for(use_dof, n_blocks, xml_file, set_xml or ())
+        block = model.block_body()
+        goals = [GoalSpec(a=block, b=goal_space, distance=geofence)] if block else None
         env_args = dict(env_args)
-        env_args.update(goals=goals, model=model, starts={}, block_space=block_space if n_blocks > 0 else None)
+        env_args.update(goals=goals, model=model, starts={}, block_space=block_space if block else None)
         return func(env_args=env_args, **kwargs)
 
     def new_function(wrapper_args, **kwargs):

@@ -144,3 +144,31 @@ def test_init_demo_shape_runs_on_the_cupboard_scene(models):
         s, r, t, i = env.step(action)
         assert s.shape == (2, 27) and np.isfinite(s).all() and not t.any()
     assert np.allclose(env.block_pos(), env.sim.body_xpos(m.body_id("block")))
+
+
+def test_cli_set_xml_and_xml_file(models):
+    """hsr/util.py:36-37,43-44,129-135: `--xml-file`, `--set-xml path,value` (last path component = attribute, the rest an
+    ElementTree path in whichever file it matches).  A known config resolves to its committed blob; a setter needs the
+    model compiler and the MJCF / STL data files."""
+    import argparse
+    from hsr_env_amd.compiler import DEFAULT_REF_ROOT
+    parser = argparse.ArgumentParser()
+    util.add_env_args(parser.add_argument_group("env_args")); util.add_wrapper_args(parser.add_argument_group("wrapper_args"))
+    args = util.hierarchical_parse_args(parser, ["--steps-per-action=300", "--geofence=.05", "--goal-space", "(0,0)(0,0)(.498,.498)",
+                                                 "--xml-file", "models/cupboard-world.xml", "--set-xml", "option/timestep,0.001",
+                                                 "--set-xml", "body/joint[@name='slide_x']/damping,1000"]
+                                        + sum([["--use-dof", d] for d in util.ALL_DOFS], []))
+    w = args["wrapper_args"]
+    assert w["set_xml"] == [util.XMLSetter("option/timestep", "0.001"), util.XMLSetter("body/joint[@name='slide_x']/damping", "1000")]
+    m = util.model_for(w["use_dof"], w["n_blocks"], w["xml_file"])
+    assert m.to_bytes() == models["cupboard"].to_bytes()
+    if not DEFAULT_REF_ROOT.exists():
+        with pytest.raises(IOError):
+            util.model_for(w["use_dof"], w["n_blocks"], w["xml_file"], w["set_xml"])
+        return
+    m2 = util.model_for(w["use_dof"], w["n_blocks"], w["xml_file"], w["set_xml"])
+    assert m2.timestep == 0.001 and m2.meta["set_xml"][0] == ["option/timestep", "0.001"]
+    i = m2.meta["dofs"].index("slide_x")
+    qa, da = m2.scalar_joints()
+    assert m2.dof_damping[da[i]] == 1000 and m2.dof_damping[da[i + 1]] == 2200          # hsr.mjcf:4,6
+    assert np.array_equal(m2.arrays["pair_geom1"], models["cupboard"].arrays["pair_geom1"])
