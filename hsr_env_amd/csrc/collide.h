@@ -276,6 +276,7 @@ __global__ void __launch_bounds__(64) k_kinematics(DevModel m, DevState s) {
     if (live) {   // link poses for k_collide / body_xpos: struct-of-arrays, one coalesced store per row
         for (int i = 0; i < 3 * m.nlink; i++) s.xpos[(size_t)i * N + e] = tl[s.kstride + i];
         for (int i = 0; i < 9 * m.nlink; i++) s.xmat[(size_t)i * N + e] = tl[s.kstride + 3 * m.nlink + i];
+        for (int i = 0; i < 6 * m.nlink; i++) s.lvel[(size_t)i * N + e] = tl[s.kstride + 12 * m.nlink + i];
     }
     if (s.want_soa_kin && live) {   // only the one-lane-per-env fallback solver reads the struct-of-arrays copies
         for (int i = 0; i < 3 * m.nv; i++) { s.dof_ang[(size_t)i * N + e] = tl[i]; s.dof_lin[(size_t)i * N + e] = tl[3 * m.nv + i]; s.dof_anchor[(size_t)i * N + e] = tl[6 * m.nv + i]; }

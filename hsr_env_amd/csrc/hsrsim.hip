@@ -296,6 +296,49 @@ __global__ void k_body_xpos(DevModel m, DevState s, int body, float *out) {
     }
     out[3 * e] = p.x; out[3 * e + 1] = p.y; out[3 * e + 2] = p.z;
 }
+// The reference's 'openai' observation (hsr/env.py:72-110, after gym's FetchEnv) with its evident intent restored
+// (SURVEY.md 8a-5 lists the defects): 25 floats per env =
+//   grip_pos 3 | object_pos 3 | object_rel_pos 3 | gripper_state 2 (finger joint qpos) | object_rot 3 (mat2euler) |
+//   object_velp 3 ((v_obj - v_grip) dt) | object_velr 3 (w_obj dt) | grip_velp 3 (v_grip dt) | gripper_vel 2 (dt/2 finger qvel)
+// body positions / velocities are those of the last forward pass (sim.data.xpos / cvel after mj_step), joint values the
+// current ones, dt = nsubsteps * timestep with nsubsteps = 1.
+__device__ __forceinline__ void body_pose_vel(const DevModel &m, const DevState &s, int body, int e, v3 &p, v3 &v, v3 &w, m3 &R) {
+    const int N = s.N, l = m.body_link[body], nl = m.nlink;
+    const View xpos{s.xpos + e, N}, xmat{s.xmat + e, N};
+    const m3 Rl = xmat.getm(l);
+    const v3 off = mulmv(Rl, ld3(m.body_pos, body));
+    p = xpos.get3(l) + off;
+    R = mulmm(Rl, ldm(m.body_mat, body));
+    w = mk3(s.lvel[(size_t)(3 * l) * N + e], s.lvel[(size_t)(3 * l + 1) * N + e], s.lvel[(size_t)(3 * l + 2) * N + e]);
+    const v3 vo = mk3(s.lvel[(size_t)(3 * nl + 3 * l) * N + e], s.lvel[(size_t)(3 * nl + 3 * l + 1) * N + e], s.lvel[(size_t)(3 * nl + 3 * l + 2) * N + e]);
+    v = vo + cross(w, off);
+}
+__global__ void k_obs_openai(DevModel m, DevState s, int body_l, int body_r, int body_obj, int qadr_l, int qadr_r, int dadr_l, int dadr_r,
+                             float dt, float *out) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= s.N) return;
+    const int N = s.N;
+    v3 pl, vl, wl, pr, vr, wr, po, vo, wo;
+    m3 Rl, Rr, Ro;
+    body_pose_vel(m, s, body_l, e, pl, vl, wl, Rl);
+    body_pose_vel(m, s, body_r, e, pr, vr, wr, Rr);
+    body_pose_vel(m, s, body_obj, e, po, vo, wo, Ro);
+    const v3 grip = (pl + pr) * 0.5f, gvel = (vl + vr) * (0.5f * dt);
+    const v3 rel = po - grip, ovel = vo * dt - gvel, orot = wo * dt;
+    // mat2euler (hsr/env.py:256-272)
+    const float cy = sqrtf(Ro.a[8] * Ro.a[8] + Ro.a[5] * Ro.a[5]);
+    const bool cond = cy > 4.f * 2.220446049250313e-16f;
+    const float ez = cond ? -atan2f(Ro.a[1], Ro.a[0]) : -atan2f(-Ro.a[3], Ro.a[4]);
+    const float ey = -atan2f(-Ro.a[2], cy);
+    const float ex = cond ? -atan2f(Ro.a[5], Ro.a[8]) : 0.f;
+    float *o = out + (size_t)25 * e;
+    o[0] = grip.x; o[1] = grip.y; o[2] = grip.z; o[3] = po.x; o[4] = po.y; o[5] = po.z; o[6] = rel.x; o[7] = rel.y; o[8] = rel.z;
+    o[9] = s.qpos[(size_t)qadr_l * N + e]; o[10] = s.qpos[(size_t)qadr_r * N + e];
+    o[11] = ex; o[12] = ey; o[13] = ez;
+    o[14] = ovel.x; o[15] = ovel.y; o[16] = ovel.z; o[17] = orot.x; o[18] = orot.y; o[19] = orot.z;
+    o[20] = gvel.x; o[21] = gvel.y; o[22] = gvel.z;
+    o[23] = 0.5f * dt * s.qvel[(size_t)dadr_l * N + e]; o[24] = 0.5f * dt * s.qvel[(size_t)dadr_r * N + e];
+}
 __global__ void k_i32_to_f32(float *dst, const int *src, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) dst[i] = (float)src[i];
@@ -429,6 +472,7 @@ extern "C" int hsr_batch_create(const hsr_model *m, int n_envs, int device_id, h
     }
     if ((rc = upload_mats(b, &d.link_mat, m, "link_quat"))) return rc;
     if ((rc = upload_mats(b, &d.geom_mat, m, "geom_quat"))) return rc;
+    if ((rc = upload_mats(b, &d.body_mat, m, "body_quat"))) return rc;
     d.any_damping = 0;
     { size_t cnt; const double *dmp = m->f64("dof_damping", &cnt); for (size_t i = 0; i < cnt; i++) if (dmp[i] > 0) d.any_damping = 1; }
 
@@ -438,7 +482,7 @@ extern "C" int hsr_batch_create(const hsr_model *m, int n_envs, int device_id, h
 #define DA(field, rows) if ((rc = dalloc(b, &s.field, (size_t)(rows) * N))) return rc;
     DA(qpos, d.nq) DA(qvel, d.nv) DA(ctrl, d.nu) DA(mocap, 3) DA(warm, d.nv) DA(time, 1)
     DA(done, 1) DA(bad, 1) DA(nsteps, 1)
-    DA(xpos, 3 * d.nlink) DA(xmat, 9 * d.nlink) DA(dof_ang, 3 * d.nv) DA(dof_lin, 3 * d.nv) DA(dof_anchor, 3 * d.nv) DA(link_dyn, 15 * d.nlink)
+    DA(xpos, 3 * d.nlink) DA(xmat, 9 * d.nlink) DA(lvel, 6 * d.nlink) DA(dof_ang, 3 * d.nv) DA(dof_lin, 3 * d.nv) DA(dof_anchor, 3 * d.nv) DA(link_dyn, 15 * d.nlink)
     s.kstride = (9 * d.nv + 15 * d.nlink + 15) & ~15;
     DA(kin_aos, s.kstride)
     DA(con, 8 * d.nslot) DA(ncon_pair, d.npair_pad) DA(sepax, 3 * std::max(d.npair, 1)) DA(pair_list, std::max(d.npair, 1))
@@ -528,7 +572,7 @@ extern "C" int hsr_batch_create(const hsr_model *m, int n_envs, int device_id, h
         if (kb > 160 * 1024) return fail(HSR_EINVAL, "kinematics tile exceeds LDS");
         if (kb > 48 * 1024) HIPCHK(hipFuncSetAttribute((const void *)k_kinematics, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kb));
     }
-    b->stage_floats = N * (size_t)(std::max(std::max(d.nq + d.nv, 7 * d.nslot), std::max(d.nv * d.nv, 9 * d.nlink)) + d.nu + d.nq + d.nv + 4) + 16;
+    b->stage_floats = N * (size_t)(std::max(std::max(std::max(d.nq + d.nv, 25), 7 * d.nslot), std::max(d.nv * d.nv, 9 * d.nlink)) + d.nu + d.nq + d.nv + 4) + 16;
     if ((rc = dalloc(b, &b->d_stage, b->stage_floats))) return rc;
     if ((rc = dalloc(b, &b->d_stage_u8, N))) return rc;
     if ((rc = dalloc(b, &b->d_stage_i32, N))) return rc;
@@ -745,6 +789,25 @@ extern "C" int hsr_batch_body_xpos(hsr_batch *b, int body_id, float *out) {
     HIPCHK(hipSetDevice(b->device));
     hipLaunchKernelGGL(k_body_xpos, grid1(b->N), dim3(256), 0, b->stream, b->dm, b->ds, body_id, b->d_stage);
     HIPCHK(hipMemcpyAsync(out, b->d_stage, (size_t)b->N * 3 * sizeof(float), hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    return HSR_OK;
+}
+
+static int obs_openai_launch(hsr_batch *b, const int *ids, float *d_out) {
+    const DevModel &d = b->dm;
+    for (int k = 0; k < 3; k++) if (ids[k] < 0 || ids[k] >= d.nbody || b->model->i32("body_mocap")[ids[k]]) return fail(HSR_EINVAL, "obs_openai: bad body id");
+    if (ids[3] < 0 || ids[3] >= d.nq || ids[4] < 0 || ids[4] >= d.nq || ids[5] < 0 || ids[5] >= d.nv || ids[6] < 0 || ids[6] >= d.nv)
+        return fail(HSR_EINVAL, "obs_openai: bad joint address");
+    HIPCHK(hipSetDevice(b->device));
+    hipLaunchKernelGGL(k_obs_openai, grid1(b->N), dim3(256), 0, b->stream, b->dm, b->ds, ids[0], ids[1], ids[2], ids[3], ids[4], ids[5], ids[6], d.timestep, d_out);
+    HIPCHK(hipGetLastError());
+    return HSR_OK;
+}
+extern "C" int hsr_batch_obs_openai_dev(hsr_batch *b, const int *ids, float *d_out) { return obs_openai_launch(b, ids, d_out); }
+extern "C" int hsr_batch_obs_openai(hsr_batch *b, const int *ids, float *out) {
+    int rc = obs_openai_launch(b, ids, b->d_stage);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(out, b->d_stage, (size_t)b->N * 25 * sizeof(float), hipMemcpyDeviceToHost, b->stream));
     HIPCHK(hipStreamSynchronize(b->stream));
     return HSR_OK;
 }

@@ -19,7 +19,7 @@ struct DevModel {
     const int *dof_link, *dof_type, *dof_parent, *dof_qposadr, *dof_limited;
     const float *dof_axis, *dof_pos, *dof_damping, *dof_invweight0, *dof_range, *dof_solref, *dof_solimp;
     const int *body_link, *body_mocap;
-    const float *body_pos;
+    const float *body_pos, *body_mat;  // body frame in its link's frame
     const int *geom_type, *geom_link, *geom_meshadr, *geom_meshnum;
     const float *geom_pos, *geom_mat, *geom_size, *geom_rbound, *geom_invweight, *mesh_vert;
     const float *geom_aabb;            // [ngeom][6] bounding box in the geom frame: centre, half extents
@@ -42,6 +42,7 @@ struct DevState {
     int *done, *bad, *nsteps;
     // kinematics outputs
     float *xpos, *xmat, *dof_ang, *dof_lin, *dof_anchor;
+    float *lvel;                      // [6 nlink][N] angular velocity, linear velocity of the link origin: same forward pass as xpos (obs kernel)
     // per-link dynamics terms from the kinematics kernel: com(3) Iworld(6: xx yy zz xy xz yz) F(3) N(3)
     float *link_dyn;
     // env-major copy of the solver's kinematic inputs: kin_aos[e][kstride] = ang[3nv] lin[3nv] anchor[3nv] link_dyn[15 nlink]

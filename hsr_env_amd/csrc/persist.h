@@ -130,6 +130,7 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(DevModel m, DevState s, i
         if (valid && (sub == n_substeps - 1 || reach)) {
             for (int i = c; i < 3 * m.nlink; i += G) s.xpos[(size_t)i * N + e] = xposL[i];
             for (int i = c; i < 9 * m.nlink; i += G) s.xmat[(size_t)i * N + e] = xmatL[i];
+            for (int i = c; i < 6 * m.nlink; i += G) s.lvel[(size_t)i * N + e] = recL[i];       // link w, v(origin): first half of the recursion scratch
         }
         // ---------------- C: collision
         // G: lane = geom, world placement of every geom once per substep (LDS, next to the link poses)

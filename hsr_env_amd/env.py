@@ -77,8 +77,10 @@ class VecHSREnv:
             raise IOError("File %s does not exist" % xml_file)          # hsr/mujoco_env.py:30-31
         if any([render, record, record_path, record_freq and False]):
             raise NotImplementedError("rendering / recording are outside the batched hot path (camera-free obs)")
-        if obs_type == "openai":
-            raise NotImplementedError("the 'openai' observation branch of the reference is dead code (SURVEY.md 8a-5)")
+        if obs_type not in (None, "openai"):
+            raise ValueError(f"unknown obs_type {obs_type!r}")
+        if obs_type == "openai" and not ({"hand_l_proximal_joint", "hand_r_proximal_joint"} <= set(model.names["joint"]) and model.block_body()):
+            raise ValueError("obs_type='openai' needs the two finger joints among the DOFs and a block (hsr/env.py:58-59,90-97)")
         self.model = model
         self.n_envs = int(n_envs)
         self.env_offset, self.n_global = int(env_offset), int(n_global or n_envs)
@@ -105,7 +107,7 @@ class VecHSREnv:
         self.action_space = Box(low=bounds[:, 0], high=bounds[:, 1], dtype=np.float32)
         self.init_qpos = model.qpos0.copy()
         self.init_qvel = np.zeros(model.nv)
-        self.obs_dim = model.nq + model.nv
+        self.obs_dim = 25 if obs_type == "openai" else model.nq + model.nv
         high = np.inf * np.ones(self.obs_dim)
         self.observation_space = Box(-high, high, dtype=np.float32)
         self._goal_body, self._geofence = -1, 0.0
@@ -193,6 +195,9 @@ class VecHSREnv:
         return self._get_observation()
 
     def _get_observation(self):
+        if self._obs_type == "openai":                                  # hsr/env.py:72-110, fused on the device
+            self._last_obs = self.sim.obs_openai()
+            return self._squeeze(self._last_obs)
         t, q, v = self.sim.get_state()
         self._last_obs = np.concatenate([q, v], axis=1)                 # hsr/env.py:111-113
         return self._squeeze(self._last_obs)
@@ -204,6 +209,8 @@ class VecHSREnv:
         goal_body = self._goal_body if self.goals else -1
         obs, rew, done, ns = self.sim.step(action, steps, goal_body, self._geofence)
         self._time_steps += 1
+        if self._obs_type == "openai":
+            obs = self.sim.obs_openai()
         self._last_obs = obs
         success = done
         info = {"log count": {"success": self._squeeze(success & (self._time_steps > 0))}, "substeps": self._squeeze(ns)}

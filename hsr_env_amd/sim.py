@@ -36,6 +36,7 @@ EXPORTS = [
     "hsr_batch_set_warmstart", "hsr_batch_get_warmstart", "hsr_batch_forward", "hsr_batch_step",
     "hsr_batch_step_dev", "hsr_batch_body_xpos", "hsr_batch_bad_state", "hsr_batch_get_field",
     "hsr_batch_set_profiling", "hsr_batch_last_timing", "hsr_batch_set_graph", "hsr_batch_set_persistent", "hsr_batch_is_persistent",
+    "hsr_batch_obs_openai", "hsr_batch_obs_openai_dev",
 ]
 
 F_XPOS, F_XMAT, F_M, F_QACC, F_QACC_SMOOTH, F_QFRC_SMOOTH, F_QFRC_CONSTRAINT, F_NCON, F_NEFC, F_CONTACT, F_NITER = range(11)
@@ -79,6 +80,8 @@ def load_library():
     L.hsr_batch_step.argtypes = [vp, fp, C.c_int, C.c_int, C.c_float, fp, fp, u8p, i32p]
     L.hsr_batch_step_dev.argtypes = [vp, vp, C.c_int, C.c_int, C.c_float, vp, vp, vp, vp]
     L.hsr_batch_body_xpos.argtypes = [vp, C.c_int, fp]
+    L.hsr_batch_obs_openai.argtypes = [vp, C.POINTER(C.c_int), fp]
+    L.hsr_batch_obs_openai_dev.argtypes = [vp, C.POINTER(C.c_int), C.c_void_p]
     L.hsr_batch_bad_state.argtypes = [vp, u8p]
     L.hsr_batch_get_field.argtypes = [vp, C.c_int, fp]
     L.hsr_batch_set_profiling.argtypes = [vp, C.c_int]
@@ -202,6 +205,24 @@ class BatchSim:
         out = np.empty((self.n, 3), np.float32)
         _check(self._L, self._L.hsr_batch_body_xpos(self._b, int(body_id), _fp(out)))
         return out
+
+    def openai_ids(self, finger_bodies=("hand_l_distal_link", "hand_r_distal_link"), object_body=None,
+                   finger_joints=("hand_l_proximal_joint", "hand_r_proximal_joint")):
+        """Body ids / joint addresses the fused 'openai' observation needs (names of hsr/env.py:58-59,90-97)."""
+        m = self.model
+        jn, qa, da = m.names["joint"], m.meta["joint_qposadr"], m.meta["joint_dofadr"]
+        ids = [m.body_id(finger_bodies[0]), m.body_id(finger_bodies[1]), m.body_id(object_body or m.block_body())]
+        ids += [qa[jn.index(j)][0] for j in finger_joints] + [da[jn.index(j)] for j in finger_joints]
+        return (C.c_int * 7)(*ids)
+
+    def obs_openai(self, ids=None):
+        """[N, 25] 'openai' observation (include/hsrsim.h: hsr_batch_obs_openai)."""
+        out = np.empty((self.n, 25), np.float32)
+        _check(self._L, self._L.hsr_batch_obs_openai(self._b, ids or self.openai_ids(), _fp(out)))
+        return out
+
+    def obs_openai_dev(self, d_out, ids=None):
+        _check(self._L, self._L.hsr_batch_obs_openai_dev(self._b, ids or self.openai_ids(), C.c_void_p(int(d_out))))
 
     def bad_state(self):
         out = np.empty(self.n, np.uint8)

@@ -85,6 +85,14 @@ int hsr_batch_step_dev(hsr_batch *b, const float *d_ctrl, int n_substeps, int go
 /* sim.data.get_body_xpos(name) for every env (hsr/env.py:144,180,184); valid after forward/step */
 int hsr_batch_body_xpos(hsr_batch *b, int body_id, float *out /*[N,3]*/);
 
+
+/* the reference's 'openai' observation (hsr/env.py:72-110, restored to its evident intent), fused in
+ * one kernel: out[N,25] = grip_pos 3 | object_pos 3 | object_rel_pos 3 | gripper_state 2 | object_rot 3 (mat2euler,
+ * hsr/env.py:256-272) | object_velp 3 | object_velr 3 | grip_velp 3 | gripper_vel 2.
+ * ids[7] = {finger body l, finger body r (hsr/env.py:59), object body (hsr/env.py:58), qpos address of the two finger
+ * joints, dof address of the two finger joints}.  Positions / velocities are those of the last forward pass. */
+int hsr_batch_obs_openai(hsr_batch *b, const int *ids, float *out /*[N,25]*/);
+int hsr_batch_obs_openai_dev(hsr_batch *b, const int *ids, float *d_out);
 /* per-env error flags (non-finite or |q| > 1e10), the batched form of MuJoCo's mj_checkPos/Vel */
 int hsr_batch_bad_state(hsr_batch *b, uint8_t *out /*[N]*/);
 

@@ -50,5 +50,38 @@ class OracleBatchSim:
     def body_xpos(self, body_id):
         return np.array([s.body_xpos(body_id) for s in self.sims], np.float32)
 
+    def obs_openai(self, ids=None):
+        # CPU stand-in: valid after reset / set_state / forward (the forward-pass state is the current state)
+        return np.array([openai_obs_reference(self.model, s.qpos.copy(), s.qvel.copy(), s.qpos, s.qvel) for s in self.sims], np.float32)
+
     def close(self):
         self.sims = []
+
+
+def openai_obs_reference(m, q_fk, v_fk, q_now, v_now, finger_bodies=("hand_l_distal_link", "hand_r_distal_link"),
+                         finger_joints=("hand_l_proximal_joint", "hand_r_proximal_joint"), object_body=None):
+    """numpy fp64 restatement of the 'openai' observation (hsr/env.py:72-110 with the intent of SURVEY.md 8a-5): body poses
+    and velocities from the forward pass at (q_fk, v_fk) (velocity of a body origin = point Jacobian x qvel, the content
+    of mj_objectVelocity), joint values from the current state, dt = timestep."""
+    from hsr_env_amd import compiler as hc
+    from hsr_env_amd.env import mat2euler
+    dt = m.timestep
+    xpos, xquat = hc.link_kinematics(m, np.asarray(q_fk, np.float64))
+    ang, lin, anchor = hc.dof_motion(m, xpos, xquat, np.asarray(q_fk, np.float64))
+
+    def body(name):
+        b = m.body_id(name)
+        l = int(m.arrays["body_link"][b])
+        R = hc.quat_to_mat(xquat[l])
+        p = xpos[l] + R @ m.arrays["body_pos"][b]
+        jp, jr = hc.point_jacobian(m, ang, lin, anchor, l, p)
+        return p, jp @ v_fk, jr @ v_fk, R @ hc.quat_to_mat(m.arrays["body_quat"][b])
+
+    pl, vl, _, _ = body(finger_bodies[0]); pr, vr, _, _ = body(finger_bodies[1])
+    po, vo, wo, Ro = body(object_body or m.block_body())
+    grip, gvel = (pl + pr) / 2, .5 * (vl + vr) * dt
+    jn = m.names["joint"]
+    qa = [m.meta["joint_qposadr"][jn.index(j)][0] for j in finger_joints]
+    da = [m.meta["joint_dofadr"][jn.index(j)] for j in finger_joints]
+    return np.concatenate([grip, po, po - grip, np.asarray(q_now)[qa], mat2euler(Ro), vo * dt - gvel, wo * dt, gvel,
+                           dt * .5 * np.asarray(v_now)[da]])

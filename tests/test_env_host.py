@@ -172,3 +172,15 @@ def test_cli_set_xml_and_xml_file(models):
     qa, da = m2.scalar_joints()
     assert m2.dof_damping[da[i]] == 1000 and m2.dof_damping[da[i + 1]] == 2200          # hsr.mjcf:4,6
     assert np.array_equal(m2.arrays["pair_geom1"], models["cupboard"].arrays["pair_geom1"])
+
+
+def test_openai_obs_type_shapes(models):
+    """obs_type='openai' (hsr/env.py:72-110): 25-dim observation from reset() and step(); needs finger joints + a block."""
+    env = make_env(models, "cfg3", 2, goals=[GoalSpec("block0", np.array([0, 0, .498]), .05)], obs_type="openai", steps_per_action=5)
+    assert env.obs_dim == 25 and env.observation_space.shape == (25,)
+    obs = env.reset()
+    assert obs.shape == (2, 25) and np.isfinite(obs).all()
+    assert np.allclose(obs[:, 6:9], obs[:, 3:6] - obs[:, 0:3], atol=1e-6)          # object_rel_pos = object_pos - grip_pos
+    assert np.allclose(obs[:, 0:3], env.gripper_pos(), atol=1e-6) and np.allclose(obs[:, 3:6], env.block_pos(), atol=1e-6)
+    with pytest.raises(ValueError):
+        make_env(models, "cfg2", 1, obs_type="openai")                                # no finger joints among the DOFs

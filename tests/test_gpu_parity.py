@@ -280,3 +280,40 @@ def test_persistent_kernel_matches_per_substep_kernels(models, cfg):
     assert ok[same_len].mean() >= 0.95, (np.sort(dq)[-5:], np.sort(dv)[-5:])
     assert np.median(dq) < 1e-6
     assert (da == db)[same_len & ok].all()
+
+
+@pytest.mark.parametrize("cfg", ["cfg3", "cupboard"])
+def test_openai_observation_matches_numpy_restatement(models, cfg):
+    """Fused obs kernel (hsr_batch_obs_openai) against the fp64 numpy restatement in tests/oracle_batch.py:
+    (1) right after set_state + forward, |d| < 2e-5; (2) after an env-step of K substeps the body poses / velocities are
+    those of the K-th forward pass and the joint values the integrated ones - compared with the oracle stepped K-1 and
+    K times, fp32 tolerance 2e-4 for >= 95 % of the envs."""
+    import sys
+    from pathlib import Path
+    sys.path.insert(0, str(Path(__file__).parent))
+    from oracle_batch import openai_obs_reference
+    m = models[cfg]
+    n = 48
+    rng = np.random.default_rng(31)
+    q, v, ctrl = random_states(m, n, rng)
+    sim = hs.BatchSim(m, n)
+    sim.set_state(np.zeros(n), q, v)
+    sim.forward()
+    got = sim.obs_openai()
+    ref = np.array([openai_obs_reference(m, q[e], v[e], q[e], v[e]) for e in range(n)])
+    assert got.shape == (n, 25) and np.abs(got - ref).max() < 2e-5, np.abs(got - ref).max(axis=0)
+    K = 12
+    sim.step(ctrl, K)
+    got = sim.obs_openai()
+    ref = []
+    for e in range(n):
+        o = OracleSim(m)
+        o.qpos[:] = q[e]; o.qvel[:] = v[e]; o.ctrl[:] = ctrl[e]
+        for _ in range(K - 1):
+            o.step()
+        qf, vf = o.qpos.copy(), o.qvel.copy()
+        o.step()
+        ref.append(openai_obs_reference(m, qf, vf, o.qpos, o.qvel))
+    err = np.abs(got - np.array(ref)).max(axis=1)
+    assert (err < 2e-4).mean() >= 0.95, np.sort(err)[-6:]
+    sim.close()
