@@ -501,7 +501,7 @@ extern "C" int hsr_batch_create(const hsr_model *m, int n_envs, int device_id, h
     s.ws_floats = o;
     DA(ws, o)
 #undef DA
-    if ((rc = dalloc(b, &s.phase_cyc, 32 + 8 * 8192))) return rc;
+    if ((rc = dalloc(b, &s.phase_cyc, 32 + 40 * 8192))) return rc;
     b->hot_threads = 64;
     b->hot_lds_bytes = (size_t)s.hot_floats * 64 * sizeof(float);
     s.hot_in_lds = b->hot_lds_bytes <= 150 * 1024 ? 1 : 0;
@@ -867,7 +867,7 @@ extern "C" int hsr_batch_block_times(hsr_batch *b, unsigned long long *out, int 
     HIPCHK(hipSetDevice(b->device));
     HIPCHK(hipStreamSynchronize(b->stream));
     if (nblocks > 8192) nblocks = 8192;
-    HIPCHK(hipMemcpy(out, b->ds.phase_cyc + 32, (size_t)nblocks * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(out, b->ds.phase_cyc + 32, (size_t)nblocks * 40 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return HSR_OK;
 }
 

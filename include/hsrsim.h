@@ -118,7 +118,7 @@ int hsr_batch_is_persistent(const hsr_batch *b);
  * tools/block_times.py): per-phase cycle sums of the last launches, and per-workgroup
  * {start, end (s_memrealtime), HW_ID, XCC_ID, Newton trips, sphere-cull candidates, work items, rows} */
 int hsr_batch_phase_cycles(hsr_batch *b, unsigned long long *out /*[32]*/);
-int hsr_batch_block_times(hsr_batch *b, unsigned long long *out /*[nblocks,8]*/, int nblocks);
+int hsr_batch_block_times(hsr_batch *b, unsigned long long *out /*[nblocks,40]: 8 header words + 26 phase cycle sums*/, int nblocks);
 
 #ifdef __cplusplus
 }

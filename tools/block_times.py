@@ -15,9 +15,9 @@ for k in range(3):
 nb = n // 4
 L = sim._L
 L.hsr_batch_block_times.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong), C.c_int]
-buf = (C.c_ulonglong * (8 * nb))()
+buf = (C.c_ulonglong * (40 * nb))()
 L.hsr_batch_block_times(sim._b, buf, nb)
-a = np.array(list(buf), dtype=np.int64).reshape(nb, 8)
+a = np.array(list(buf), dtype=np.int64).reshape(nb, 40)
 t0 = a[:, 0].min()
 st = (a[:, 0] - t0) / 100.0; en = (a[:, 1] - t0) / 100.0       # us
 print('blocks', nb, 'kernel span %.1f ms' % (en.max() / 1e3))
@@ -43,3 +43,13 @@ print('corr(life, newton) %.3f  corr(life, items) %.3f corr(life, nefc) %.3f' % 
 A = np.stack([np.ones(nb), a[:, 4], a[:, 6], a[:, 7]], 1).astype(np.float64)
 coef = np.linalg.lstsq(A, life * 300 / 300, rcond=None)[0]
 print('life us ~ %.0f + %.2f * newton_trips + %.2f * items + %.2f * nefc' % tuple(coef))
+
+names = ['A load', 'B/C M+bias', 'D chol M', 'E1-2', 'E3', 'E4-5', 'F0 warm', 'F grad', 'F hess', 'F chol', 'F ls', 'F eval', 'G(12)', '(13)', 'exit+qfc(14)', 'G chol(15)',
+         'K kin(16)', 'C(17)', 'integrate(18)', 'C cull1(19)', 'C cull2(20)', 'C plane(21)', 'C mpr(22)', 'C boxbox(23)', '-', '-']
+ph = a[:, 8:34].astype(np.float64) / 300.0
+slow, med = o[-20:], o[nb // 2 - 10: nb // 2 + 10]
+print('phase cycles per substep: slowest 20 blocks vs 20 median blocks')
+for i, nm in enumerate(names):
+    if ph[:, i].sum() > 0:
+        print(f'  {nm:14s} {ph[slow, i].mean():9.0f} {ph[med, i].mean():9.0f}')
+print(f'  {"total":14s} {ph[slow].sum(1).mean():9.0f} {ph[med].sum(1).mean():9.0f}')
