@@ -169,6 +169,30 @@ __device__ __forceinline__ void cone_eval2(int dim, float mu, const float *fri, 
     o.cost = 0.5f * Dm * NT * NT;
 }
 
+// first and second derivative along v of the elliptic-cone cost at residual x (what the line search needs): the same
+// zones and formulas as cone_eval2 contracted with v analytically, d1 = g . v, d2 = v^T (diag(dw) + Dm gn gn^T - k3 u u^T) v
+__device__ __forceinline__ void cone_dd(int dim, float mu, const float *fri, const float *D, const float *x, const float *v, float &d1, float &d2) {
+    d1 = 0; d2 = 0;
+    const float Nn = x[0] * mu;
+    float T2 = 0, S1 = 0, S2 = 0;
+#pragma unroll
+    for (int j = 1; j < 6; j++) {
+        const float f = (j < dim) ? fri[j - 1] : 0.f, Uj = x[j] * f, fv = f * v[j];
+        T2 += Uj * Uj; S1 += Uj * fv; S2 += fv * fv;
+    }
+    const float T = sqrtf(T2);
+    if (Nn >= mu * T || (T <= 0 && Nn >= 0)) return;
+    if (mu * Nn + T <= 0 || (T <= 0 && Nn < 0)) {
+#pragma unroll
+        for (int j = 0; j < 6; j++) if (j < dim) { d1 += D[j] * x[j] * v[j]; d2 += D[j] * v[j] * v[j]; }
+        return;
+    }
+    const float Dm = D[0] / (mu * mu * (1 + mu * mu)), NT = Nn - mu * T, invT = 1.0f / T;
+    const float kappa = -Dm * NT * mu, gnv = mu * (v[0] - invT * S1);
+    d1 = Dm * NT * gnv;
+    d2 = kappa * invT * S2 + Dm * gnv * gnv - (kappa * invT / T2) * S1 * S1;
+}
+
 // per-contact record in LDS (floats)
 enum { CR_POS = 0, CR_N = 3, CR_T1 = 6, CR_T2 = 9, CR_DIST = 12, CR_MU = 13, CR_PAIR = 14, CR_ADR = 15, CR_DIM = 16,
        CR_ZONE = 17, CR_DM = 18, CR_K3 = 19, CR_GN = 20, CR_U = 26, CR_L1 = 32, CR_L2 = 33, CR_B = 34, CR_KD = 35, CR_FRI = 36, CR_SIZE = 41 };
