@@ -16,7 +16,7 @@ def build_lib(force: bool = False, verbose: bool = False, timing: bool = False) 
     deps = list((HERE / "csrc").glob("*")) + [HERE.parent / "include" / "hsrsim.h"]
     if not force and out.exists() and all(out.stat().st_mtime >= d.stat().st_mtime for d in deps):
         return out
-    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-result", "-Wno-unused-value",
+    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-shared", "-fPIC", "-Wno-unused-result", "-Wno-unused-value",
            "-o", str(out), str(SRC)]
     if timing:
         cmd.append("-DHSR_PHASE_TIMING")
