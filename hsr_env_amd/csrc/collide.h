@@ -326,8 +326,8 @@ template <int W = 1> __device__ __forceinline__ v3 support(const Geom &G, v3 dir
     if (G.type == GEOM_BOX) {
         loc = mk3(dl.x > 0 ? G.size.x : -G.size.x, dl.y > 0 ? G.size.y : -G.size.y, dl.z > 0 ? G.size.z : -G.size.z);
     } else if (G.type == GEOM_CYLINDER) {
-        const float rr = sqrtf(dl.x * dl.x + dl.y * dl.y);
-        if (rr > HSR_MINVAL) { loc.x = dl.x / rr * G.size.x; loc.y = dl.y / rr * G.size.x; } else { loc.x = 0; loc.y = 0; }
+        const float r2 = dl.x * dl.x + dl.y * dl.y, ir = frsq(r2);
+        if (r2 > HSR_MINVAL * HSR_MINVAL) { loc.x = dl.x * ir * G.size.x; loc.y = dl.y * ir * G.size.x; } else { loc.x = 0; loc.y = 0; }
         loc.z = dl.z > 0 ? G.size.y : -G.size.y;
     } else if (G.type == GEOM_SPHERE) {
         loc = normalized(dl) * G.size.x;
@@ -429,7 +429,7 @@ __device__ __forceinline__ int clip_poly(float *poly, int pstride, int poff, int
         const float da = dot(a - origin, axis) - lim, db = dot(b - origin, axis) - lim;
         if (da <= 0 && no < 8) { POLY(dst, no, 0) = a.x; POLY(dst, no, 1) = a.y; POLY(dst, no, 2) = a.z; no++; }
         if (((da < 0 && db > 0) || (da > 0 && db < 0)) && no < 8) {
-            const float t = da / (da - db);
+            const float t = da * frcp(da - db);
             POLY(dst, no, 0) = a.x + t * (b.x - a.x); POLY(dst, no, 1) = a.y + t * (b.y - a.y); POLY(dst, no, 2) = a.z + t * (b.z - a.z);
             no++;
         }
@@ -476,7 +476,7 @@ __device__ __forceinline__ void collide_box_box_p(const Geom &G1, const Geom &G2
             v3 L = cross(A[i], B[j]);
             const float ln = norm(L);
             if (ln < 1e-6f) continue;
-            L = L * (1.0f / ln);
+            L = L * frcp(ln);
             const float t = dot(dv, L);
             float ra = 0, rb = 0;
 #pragma unroll
@@ -672,7 +672,7 @@ template <int W = 1> __device__ bool mpr_penetration(const Geom &G1, const Geom 
         if (reach_tol(p1, p2, p3, v4, dir, tol) || it > maxit) {
             v3 pdir;
             bool interior;
-            depth = sqrtf(point_tri_dist2(p1.v, p2.v, p3.v, pdir, interior));
+            depth = fsqrt(point_tri_dist2(p1.v, p2.v, p3.v, pdir, interior));
             if (interior) {
                 // the witness is the foot of the perpendicular: depth = |n . v1|, direction = +-n
                 const float dn = dot(dir, p1.v);
@@ -690,7 +690,7 @@ template <int W = 1> __device__ bool mpr_penetration(const Geom &G1, const Geom 
                 b0 = 0; b1 = dot(cross(p2.v, p3.v), dir); b2 = dot(cross(p3.v, p1.v), dir); b3 = dot(cross(p1.v, p2.v), dir);
                 sum = b1 + b2 + b3;
             }
-            const float inv = 0.5f / sum;
+            const float inv = 0.5f * frcp(sum);
             pos = (p0.v1 * b0 + p1.v1 * b1 + p2.v1 * b2 + p3.v1 * b3 + p0.v2 * b0 + p1.v2 * b1 + p2.v2 * b2 + p3.v2 * b3) * inv;
             return true;
         }

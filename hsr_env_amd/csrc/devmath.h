@@ -7,6 +7,12 @@
 #define HSR_MAXIMP 0.9999f
 #define HSR_EPS 1.1920929e-7f
 
+// 1-ulp hardware reciprocal / square root (v_rcp_f32, v_sqrt_f32, v_rsq_f32) instead of the ~10-instruction IEEE
+// sequences: the fp32 path is checked against the fp64 oracle at tolerances far above an ulp
+__device__ __forceinline__ float frcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float fsqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+__device__ __forceinline__ float frsq(float x) { return __builtin_amdgcn_rsqf(x); }
+
 struct v3 { float x, y, z; };
 struct m3 { float a[9]; };   // row-major
 
@@ -20,12 +26,11 @@ __device__ __forceinline__ float dot(v3 a, v3 b) { return a.x * b.x + a.y * b.y 
 __device__ __forceinline__ v3 cross(v3 a, v3 b) {
     return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
 }
-__device__ __forceinline__ float norm(v3 a) { return sqrtf(dot(a, a)); }
+__device__ __forceinline__ float norm(v3 a) { return fsqrt(dot(a, a)); }
 __device__ __forceinline__ v3 normalized(v3 a) {
-    float n = norm(a);
-    if (n < HSR_MINVAL) return mk3(1.f, 0.f, 0.f);
-    float inv = 1.0f / n;
-    return a * inv;
+    const float d = dot(a, a);
+    if (d < HSR_MINVAL * HSR_MINVAL) return mk3(1.f, 0.f, 0.f);
+    return a * frsq(d);
 }
 __device__ __forceinline__ float comp(v3 a, int k) { return k == 0 ? a.x : (k == 1 ? a.y : a.z); }
 __device__ __forceinline__ v3 mulmv(const m3 &m, v3 v) {
@@ -56,9 +61,9 @@ __device__ __forceinline__ q4 qmul(q4 a, q4 b) {
     return r;
 }
 __device__ __forceinline__ q4 qnormalized(q4 q) {
-    float n = sqrtf(q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z);
-    if (n < HSR_MINVAL) { q.w = 1.f; q.x = q.y = q.z = 0.f; return q; }
-    float inv = 1.0f / n;
+    const float d = q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z;
+    if (d < HSR_MINVAL * HSR_MINVAL) { q.w = 1.f; q.x = q.y = q.z = 0.f; return q; }
+    const float inv = frsq(d);
     q.w *= inv; q.x *= inv; q.y *= inv; q.z *= inv;
     return q;
 }

@@ -145,7 +145,7 @@ __device__ __forceinline__ void cone_eval2(int dim, float mu, const float *fri, 
     const float Nn = U[0];
 #pragma unroll
     for (int j = 1; j < 6; j++) { U[j] = (j < dim) ? x[j] * fri[j - 1] : 0.f; T2 += U[j] * U[j]; }
-    const float T = sqrtf(T2);
+    const float T = fsqrt(T2);
     if (Nn >= mu * T || (T <= 0 && Nn >= 0)) return;
     if (mu * Nn + T <= 0 || (T <= 0 && Nn < 0)) {
         o.zone = 1;
@@ -154,9 +154,9 @@ __device__ __forceinline__ void cone_eval2(int dim, float mu, const float *fri, 
         return;
     }
     o.zone = 2;
-    const float Dm = D[0] / (mu * mu * (1 + mu * mu)), NT = Nn - mu * T, invT = 1.0f / T;
+    const float Dm = D[0] * frcp(mu * mu * (1 + mu * mu)), NT = Nn - mu * T, invT = frcp(T);
     const float kappa = -Dm * NT * mu;
-    o.Dm = Dm; o.k3 = kappa * invT / T2;
+    o.Dm = Dm; o.k3 = kappa * invT * frcp(T2);
     o.gn[0] = mu;
 #pragma unroll
     for (int j = 1; j < 6; j++) if (j < dim) {
@@ -180,17 +180,17 @@ __device__ __forceinline__ void cone_dd(int dim, float mu, const float *fri, con
         const float f = (j < dim) ? fri[j - 1] : 0.f, Uj = x[j] * f, fv = f * v[j];
         T2 += Uj * Uj; S1 += Uj * fv; S2 += fv * fv;
     }
-    const float T = sqrtf(T2);
+    const float T = fsqrt(T2);
     if (Nn >= mu * T || (T <= 0 && Nn >= 0)) return;
     if (mu * Nn + T <= 0 || (T <= 0 && Nn < 0)) {
 #pragma unroll
         for (int j = 0; j < 6; j++) if (j < dim) { d1 += D[j] * x[j] * v[j]; d2 += D[j] * v[j] * v[j]; }
         return;
     }
-    const float Dm = D[0] / (mu * mu * (1 + mu * mu)), NT = Nn - mu * T, invT = 1.0f / T;
+    const float Dm = D[0] * frcp(mu * mu * (1 + mu * mu)), NT = Nn - mu * T, invT = frcp(T);
     const float kappa = -Dm * NT * mu, gnv = mu * (v[0] - invT * S1);
     d1 = Dm * NT * gnv;
-    d2 = kappa * invT * S2 + Dm * gnv * gnv - (kappa * invT / T2) * S1 * S1;
+    d2 = kappa * invT * S2 + Dm * gnv * gnv - (kappa * invT * frcp(T2)) * S1 * S1;
 }
 
 // per-contact record in LDS (floats)
