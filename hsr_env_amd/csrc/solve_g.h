@@ -169,6 +169,23 @@ __device__ __forceinline__ void cone_eval2(int dim, float mu, const float *fri, 
     o.cost = 0.5f * Dm * NT * NT;
 }
 
+// cost only (the warm-start comparison needs nothing else at the unconstrained point)
+__device__ __forceinline__ float cone_cost(int dim, float mu, const float *fri, const float *D, const float *x) {
+    const float Nn = x[0] * mu;
+    float T2 = 0;
+#pragma unroll
+    for (int j = 1; j < 6; j++) { const float Uj = (j < dim) ? x[j] * fri[j - 1] : 0.f; T2 += Uj * Uj; }
+    const float T = fsqrt(T2);
+    if (Nn >= mu * T || (T <= 0 && Nn >= 0)) return 0.f;
+    if (mu * Nn + T <= 0 || (T <= 0 && Nn < 0)) {
+        float cst = 0;
+#pragma unroll
+        for (int j = 0; j < 6; j++) if (j < dim) cst += 0.5f * D[j] * x[j] * x[j];
+        return cst;
+    }
+    const float Dm = D[0] * frcp(mu * mu * (1 + mu * mu)), NT = Nn - mu * T;
+    return 0.5f * Dm * NT * NT;
+}
 // first and second derivative along v of the elliptic-cone cost at residual x (what the line search needs): the same
 // zones and formulas as cone_eval2 contracted with v analytically, d1 = g . v, d2 = v^T (diag(dw) + Dm gn gn^T - k3 u u^T) v
 __device__ __forceinline__ void cone_dd(int dim, float mu, const float *fri, const float *D, const float *x, const float *v, float &d1, float &d2) {
