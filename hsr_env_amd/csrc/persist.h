@@ -300,6 +300,8 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(DevModel m, DevState s, i
             if (c == my_quat_lane && my_type == DOF_FREE_ANG) { quat0.w = qposL[my_qadr]; quat0.x = qposL[my_qadr + 1]; quat0.y = qposL[my_qadr + 2]; quat0.z = qposL[my_qadr + 3]; }
         }
         __syncthreads();             // qposL / link poses are read; region B may now be reused by the solver
+        float *lvbuf = reinterpret_cast<float *>(pcnt);       // the pair counts are in registers (cnt_ch): their LDS words are free
+        const int lvcap = ((m.npair_pad + 3) / 4) / 6;
         {
 #define SOLVE_STORE_DIAG false
 #include "solve_body.inc"

@@ -70,6 +70,16 @@ template <int G> __device__ __forceinline__ int gscan_incl(int v, int c) {
         return v;
     }
 }
+template <int G> __device__ __forceinline__ int gor(int v) {     // bitwise OR over the group, in every lane
+    if constexpr (G == 16) {
+        v |= dpp_i<0x128, true>(v); v |= dpp_i<0x124, true>(v); v |= dpp_i<0x122, true>(v); v |= dpp_i<0x121, true>(v);
+        return v;
+    } else {
+#pragma unroll
+        for (int off = G / 2; off > 0; off >>= 1) v |= __shfl_xor(v, off, G);
+        return v;
+    }
+}
 template <int G> __device__ __forceinline__ int glast(int v) {   // value of the last lane of the group
     if constexpr (G == 16) return dpp_i<0x15F, false>(v); else return __shfl(v, G - 1, G);
 }

@@ -19,13 +19,14 @@ enum { C2_POS = 0, C2_L1 = 3, C2_N = 4, C2_L2 = 7, C2_T1 = 8, C2_ADR = 11, C2_T2
 __device__ __forceinline__ float4 lds4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 
 template <int G> struct MfLayout {
-    int R, MS, oRows, oB, total;
+    int R, MS, oRows, oB, oLv, total;
     __host__ __device__ MfLayout(int rows, int kstride) {
         R = rows; MS = G + 1;
         const int a = 6 * R > kstride ? 6 * R : kstride;                    // row scalars; the kin record aliases them early on
         const int b = G * MS > C2_SIZE * G ? G * MS : C2_SIZE * G;          // inertia matrix, then contact records
         oRows = 0; oB = (a + 3) & ~3;
-        total = (oB + b + 3) & ~3;
+        oLv = (oB + b + 3) & ~3;                                            // per-link velocity fields of jmul: 5 links x 6
+        total = oLv + 32;
     }
 };
 
@@ -70,6 +71,8 @@ __global__ void __launch_bounds__(64, 2) k_solve_mf(DevModel m, DevState s, int 
     float *rD = E + L.oRows, *rAref = rD + R, *rJar = rAref + R, *rJv = rJar + R, *rGr = rJv + R, *rDw = rGr + R;
     float *kAng = E + L.oRows, *kLin = kAng + 3 * nv, *kAnc = kAng + 6 * nv, *lk = kAng + 9 * nv;     // kin_aos record (phases A-C)
     float *M = E + L.oB, *con = E + L.oB;
+    float *lvbuf = E + L.oLv;
+    const int lvcap = 5;
     const bool isdof = c < nv;
     int bad = 0;
     __shared__ int sParent[32], sMask[NLMAX];
