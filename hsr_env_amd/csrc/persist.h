@@ -111,6 +111,7 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(DevModel m, DevState s, i
                 if (valid && mydepth == dlev) kin_link_pose(K, c, vq, vx, vm, va, vl, vn);
                 __syncthreads();
             }
+            PHASE(24);
             for (int dlev = 1; dlev <= m.maxdepth; dlev++) {
                 if (valid && mydepth == dlev) kin_link_dyn(K, m.gravz, c, vv, vx, vm, va, vl, vn, vd, w0, w1, w2, w3);
                 __syncthreads();
