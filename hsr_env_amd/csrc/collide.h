@@ -550,6 +550,161 @@ __device__ __forceinline__ void collide_box_box_p(const Geom &G1, const Geom &G2
 __device__ __forceinline__ void collide_box_box(const Geom &G1, const Geom &G2, ContactOut &out, float *poly, int lane) { collide_box_box_p(G1, G2, out, poly, 64, lane); }
 __device__ __forceinline__ void collide_box_box_slot(const Geom &G1, const Geom &G2, ContactOut &out, float *slot) { collide_box_box_p(G1, G2, out, slot, 1, 0); }
 
+// --- box-box for an 8-lane sub-group (all 8 lanes hold the same pair): the same routine as collide_box_box_p, element for
+// element, with the expensive parts spread over the lanes: the nine edge-edge axes are evaluated one per lane and folded in
+// the sequential order afterwards; the clipped polygon lives one vertex per lane, a clip is a neighbour exchange, a width-8
+// scan of the emitted counts and a scatter through 24 floats of LDS.  Returns the number of contacts written.
+__device__ __forceinline__ v3 shfl3_8(v3 a, int src) { return mk3(__shfl(a.x, src, 8), __shfl(a.y, src, 8), __shfl(a.z, src, 8)); }
+__device__ __forceinline__ int collide_box_box_w8(const Geom &G1, const Geom &G2, float *con, int slot, int maxcnt, volatile float *scr) {
+    const int sub = threadIdx.x & 7;
+    v3 A[3], B[3];
+    float s1[3] = {G1.size.x, G1.size.y, G1.size.z}, s2[3] = {G2.size.x, G2.size.y, G2.size.z};
+#pragma unroll
+    for (int i = 0; i < 3; i++) { A[i] = col(G1.mat, i); B[i] = col(G2.mat, i); }
+    const v3 dv = G2.pos - G1.pos;
+    float aC[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) aC[i][j] = fabsf(dot(A[i], B[j]));
+    float best = -3.0e38f;
+    int code = -1;
+    v3 bestn = mk3(0, 0, 0);
+    bool sepfound = false;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        const float t = dot(dv, A[i]);
+        const float sep = fabsf(t) - (s1[i] + s2[0] * aC[i][0] + s2[1] * aC[i][1] + s2[2] * aC[i][2]);
+        if (sep > 0) sepfound = true;
+        if (sep > best) { best = sep; code = i; bestn = A[i] * (t < 0 ? -1.f : 1.f); }
+    }
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        const float t = dot(dv, B[j]);
+        const float sep = fabsf(t) - (s2[j] + s1[0] * aC[0][j] + s1[1] * aC[1][j] + s1[2] * aC[2][j]);
+        if (sep > 0) sepfound = true;
+        if (sep > best) { best = sep; code = 3 + j; bestn = B[j] * (t < 0 ? -1.f : 1.f); }
+    }
+    if (sepfound) return 0;
+    // edge axes q = 3 i + j: lane q evaluates axis q, lane 0 also axis 8
+    float esep[2];
+    int eok[2];
+    v3 eL[2];
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        const int q = r == 0 ? sub : 8, i = q / 3, j = q - 3 * i;
+        const v3 Ai = i == 0 ? A[0] : (i == 1 ? A[1] : A[2]), Bj = j == 0 ? B[0] : (j == 1 ? B[1] : B[2]);
+        v3 L = cross(Ai, Bj);
+        const float ln = norm(L);
+        eok[r] = ln < 1e-6f ? 0 : 1;
+        L = L * frcp(ln);
+        const float t = dot(dv, L);
+        float ra = 0, rb = 0;
+#pragma unroll
+        for (int k = 0; k < 3; k++) { ra += s1[k] * fabsf(dot(A[k], L)); rb += s2[k] * fabsf(dot(B[k], L)); }
+        esep[r] = fabsf(t) - (ra + rb);
+        eL[r] = L * (t < 0 ? -1.f : 1.f);
+    }
+#pragma unroll
+    for (int q = 0; q < 9; q++) {
+        const float sep = q < 8 ? __shfl(esep[0], q, 8) : __shfl(esep[1], 0, 8);
+        const int ok = q < 8 ? __shfl(eok[0], q, 8) : __shfl(eok[1], 0, 8);
+        if (ok) {
+            if (sep > 0) sepfound = true;
+            if (sep * 1.05f > best + 1e-9f) { best = sep; code = 6 + q; }
+        }
+    }
+    if (sepfound) return 0;
+    if (code >= 6) bestn = code < 14 ? shfl3_8(eL[0], code - 6) : shfl3_8(eL[1], 0);
+    if (code < 6) {
+        const bool ref1 = code < 3;
+        const int ax = ref1 ? code : code - 3;
+        const v3 pr = ref1 ? G1.pos : G2.pos, pi = ref1 ? G2.pos : G1.pos;
+        v3 Ar[3], Ai[3];
+        float sr[3], si[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) { Ar[k] = ref1 ? A[k] : B[k]; Ai[k] = ref1 ? B[k] : A[k]; sr[k] = ref1 ? s1[k] : s2[k]; si[k] = ref1 ? s2[k] : s1[k]; }
+        const v3 nref = bestn * (ref1 ? 1.f : -1.f);
+        int jx = 0;
+        float bd = -1.f;
+#pragma unroll
+        for (int j = 0; j < 3; j++) { const float t = fabsf(dot(nref, Ai[j])); if (t > bd) { bd = t; jx = j; } }
+        const v3 Aj = jx == 0 ? Ai[0] : (jx == 1 ? Ai[1] : Ai[2]);
+        const v3 Aj1 = jx == 0 ? Ai[1] : (jx == 1 ? Ai[2] : Ai[0]);
+        const v3 Aj2 = jx == 0 ? Ai[2] : (jx == 1 ? Ai[0] : Ai[1]);
+        const float sj = jx == 0 ? si[0] : (jx == 1 ? si[1] : si[2]);
+        const float sj1 = jx == 0 ? si[1] : (jx == 1 ? si[2] : si[0]);
+        const float sj2 = jx == 0 ? si[2] : (jx == 1 ? si[0] : si[1]);
+        const float sgn = dot(nref, Aj) > 0 ? -1.f : 1.f;
+        const v3 fc = pi + Aj * (sgn * sj);
+        // incident face, vertex k on lane k: signs (1,1) (-1,1) (-1,-1) (1,-1)
+        const float sgx = (sub == 0 || sub == 3) ? 1.f : -1.f, sgy = sub < 2 ? 1.f : -1.f;
+        v3 P = fc + Aj1 * (sgx * sj1) + Aj2 * (sgy * sj2);
+        const v3 Au = ax == 0 ? Ar[1] : (ax == 1 ? Ar[2] : Ar[0]);
+        const v3 Av = ax == 0 ? Ar[2] : (ax == 1 ? Ar[0] : Ar[1]);
+        const float su = ax == 0 ? sr[1] : (ax == 1 ? sr[2] : sr[0]);
+        const float sv = ax == 0 ? sr[2] : (ax == 1 ? sr[0] : sr[1]);
+        const float sa = ax == 0 ? sr[0] : (ax == 1 ? sr[1] : sr[2]);
+        int np = 4;
+        auto clip = [&](v3 axis, float lim) {
+            const v3 b = shfl3_8(P, (sub + 1 >= np) ? 0 : sub + 1);
+            const float da = dot(P - pr, axis) - lim, db = dot(b - pr, axis) - lim;
+            const bool have = sub < np;
+            const int in = (have && da <= 0) ? 1 : 0, cr = (have && ((da < 0 && db > 0) || (da > 0 && db < 0))) ? 1 : 0;
+            int incl = in + cr;
+#pragma unroll
+            for (int d = 1; d < 8; d <<= 1) { const int t = __shfl_up(incl, d, 8); if (sub >= d) incl += t; }
+            const int base = incl - in - cr, total = __shfl(incl, 7, 8);
+            if (in && base < 8) { scr[3 * base] = P.x; scr[3 * base + 1] = P.y; scr[3 * base + 2] = P.z; }
+            if (cr && base + in < 8) {
+                const float t = da * frcp(da - db);
+                const int o = 3 * (base + in);
+                scr[o] = P.x + t * (b.x - P.x); scr[o + 1] = P.y + t * (b.y - P.y); scr[o + 2] = P.z + t * (b.z - P.z);
+            }
+            np = total < 8 ? total : 8;
+            __builtin_amdgcn_wave_barrier();
+            P = mk3(scr[3 * sub], scr[3 * sub + 1], scr[3 * sub + 2]);
+            __builtin_amdgcn_wave_barrier();
+        };
+        clip(Au, su);
+        if (np) clip(-Au, su);
+        if (np) clip(Av, sv);
+        if (np) clip(-Av, sv);
+        const float dist = dot(P - pr, nref) - sa;
+        const bool hit = sub < np && dist < 0;
+        const unsigned int hm = (unsigned int)((__ballot(hit) >> (threadIdx.x & 56)) & 0xffull);
+        const int rank = __popc(hm & ((1u << sub) - 1u)), nh = __popc(hm);
+        if (hit && rank < maxcnt) {
+            const v3 pos = P - nref * (0.5f * dist);
+            float4 *r = reinterpret_cast<float4 *>(con + (size_t)(slot + rank) * 8);
+            r[0] = make_float4(pos.x, pos.y, pos.z, bestn.x);
+            r[1] = make_float4(bestn.y, bestn.z, dist, 0.f);
+        }
+        return nh < maxcnt ? nh : maxcnt;
+    }
+    {
+        const int i = (code - 6) / 3, j = (code - 6) % 3;
+        v3 pa = G1.pos, pb = G2.pos;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            if (k != i) pa = pa + A[k] * ((dot(bestn, A[k]) > 0 ? 1.f : -1.f) * s1[k]);
+            if (k != j) pb = pb + B[k] * ((dot(bestn, B[k]) > 0 ? -1.f : 1.f) * s2[k]);
+        }
+        const v3 Ai_ = i == 0 ? A[0] : (i == 1 ? A[1] : A[2]);
+        const v3 Bj_ = j == 0 ? B[0] : (j == 1 ? B[1] : B[2]);
+        const v3 w = pa - pb;
+        const float b = dot(Ai_, Bj_), dd = dot(Ai_, w), ee = dot(Bj_, w), den = 1.f - b * b;
+        const float t = den > 1e-12f ? (b * ee - dd) / den : 0.f, uu = den > 1e-12f ? (ee - b * dd) / den : 0.f;
+        const v3 qa = pa + Ai_ * t, qb = pb + Bj_ * uu, pos = (qa + qb) * 0.5f;
+        if (sub == 0 && maxcnt > 0) {
+            float4 *r = reinterpret_cast<float4 *>(con + (size_t)slot * 8);
+            r[0] = make_float4(pos.x, pos.y, pos.z, bestn.x);
+            r[1] = make_float4(bestn.y, bestn.z, best, 0.f);
+        }
+        return maxcnt > 0 ? 1 : 0;
+    }
+}
+
 // --- convex-convex: Minkowski Portal Refinement (libccd ccdMPRPenetration as used by mjc_Convex)
 struct Sup { v3 v, v1, v2; };
 #ifdef HSR_PHASE_TIMING

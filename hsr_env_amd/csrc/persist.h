@@ -244,22 +244,22 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(DevModel m, DevState s, i
                     }
                 }
                 PHASE(22);
-                // box-box needs LDS polygon scratch: at most 4 lanes of the wave run it at a time
+                // box-box: one work item per 8-lane sub-group as well (edge axes and polygon vertices spread over the lanes)
                 {
                     const bool bb = fn == FN_BOX_BOX;
-                    unsigned long long pend = __ballot(bb);
-                    while (pend) {
-                        const int rank = __popcll(pend & ((1ull << tid) - 1ull));
-                        const bool mine = bb && ((pend >> tid) & 1ull) && rank < 4;
-                        if (mine) {
+                    const unsigned long long bbal = __ballot(bb);
+                    __syncthreads();                                 // sMpr is reused as the box-box item list
+                    if (bb) sMpr[__popcll(bbal & ((1ull << tid) - 1ull))] = (unsigned char)tid;
+                    const int nbb = __popcll(bbal);
+                    __syncthreads();
+                    for (int r0 = 0; r0 < nbb; r0 += 8) {
+                        const int k = r0 + tid / 8;
+                        if (k < nbb) {
                             Geom G1, G2; ContactOut out; unsigned char *cntp;
-                            item_geoms(it, G1, G2, out, cntp);
-                            collide_box_box_slot(G1, G2, out, poly + 48 * rank);
-                            *cntp = (unsigned char)out.cnt;
+                            item_geoms(sItems[sMpr[k]], G1, G2, out, cntp);
+                            const int cnt = collide_box_box_w8(G1, G2, out.con, out.slot, out.maxcnt, poly + 24 * (tid / 8));
+                            if ((tid & 7) == 0) *cntp = (unsigned char)cnt;
                         }
-                        unsigned long long t = pend; int k = 0;
-                        while (t && k < 4) { t &= t - 1; k++; }
-                        pend = t;
                     }
                 }
                 PHASE(23);
