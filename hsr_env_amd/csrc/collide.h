@@ -555,6 +555,13 @@ __device__ __forceinline__ void collide_box_box_slot(const Geom &G1, const Geom 
 // the sequential order afterwards; the clipped polygon lives one vertex per lane, a clip is a neighbour exchange, a width-8
 // scan of the emitted counts and a scatter through 24 floats of LDS.  Returns the number of contacts written.
 __device__ __forceinline__ v3 shfl3_8(v3 a, int src) { return mk3(__shfl(a.x, src, 8), __shfl(a.y, src, 8), __shfl(a.z, src, 8)); }
+// DPP moves inside an 8-lane sub-group (two sub-groups per 16-lane DPP row): broadcast of sub-group lane Q, value of the next
+// lane, value D lanes below (callers guard the lanes that would read across the sub-group boundary)
+template <int CTRL> __device__ __forceinline__ int dppi_(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true); }
+template <int CTRL> __device__ __forceinline__ float dppf_(float v) { return __builtin_bit_cast(float, dppi_<CTRL>(__builtin_bit_cast(int, v))); }
+template <int Q> __device__ __forceinline__ int sg8_bcast(int v) { const int lo = dppi_<0x150 + Q>(v), hi = dppi_<0x158 + Q>(v); return (threadIdx.x & 8) ? hi : lo; }
+template <int Q> __device__ __forceinline__ float sg8_bcast(float v) { return __builtin_bit_cast(float, sg8_bcast<Q>(__builtin_bit_cast(int, v))); }
+__device__ __forceinline__ float sg8_next(float v) { return dppf_<0x101>(v); }
 __device__ __forceinline__ int collide_box_box_w8(const Geom &G1, const Geom &G2, float *con, int slot, int maxcnt, volatile float *scr) {
     const int sub = threadIdx.x & 7;
     v3 A[3], B[3];
@@ -605,15 +612,15 @@ __device__ __forceinline__ int collide_box_box_w8(const Geom &G1, const Geom &G2
         esep[r] = fabsf(t) - (ra + rb);
         eL[r] = L * (t < 0 ? -1.f : 1.f);
     }
-#pragma unroll
-    for (int q = 0; q < 9; q++) {
-        const float sep = q < 8 ? __shfl(esep[0], q, 8) : __shfl(esep[1], 0, 8);
-        const int ok = q < 8 ? __shfl(eok[0], q, 8) : __shfl(eok[1], 0, 8);
+    static_for<0, 9>([&](auto qc) {
+        constexpr int q = decltype(qc)::value;
+        const float sep = q < 8 ? sg8_bcast<q & 7>(esep[0]) : sg8_bcast<0>(esep[1]);
+        const int ok = q < 8 ? sg8_bcast<q & 7>(eok[0]) : sg8_bcast<0>(eok[1]);
         if (ok) {
             if (sep > 0) sepfound = true;
             if (sep * 1.05f > best + 1e-9f) { best = sep; code = 6 + q; }
         }
-    }
+    });
     if (sepfound) return 0;
     if (code >= 6) bestn = code < 14 ? shfl3_8(eL[0], code - 6) : shfl3_8(eL[1], 0);
     if (code < 6) {
@@ -647,14 +654,19 @@ __device__ __forceinline__ int collide_box_box_w8(const Geom &G1, const Geom &G2
         const float sa = ax == 0 ? sr[0] : (ax == 1 ? sr[1] : sr[2]);
         int np = 4;
         auto clip = [&](v3 axis, float lim) {
-            const v3 b = shfl3_8(P, (sub + 1 >= np) ? 0 : sub + 1);
+            const bool wrap = sub + 1 >= np;
+            // both moves are executed by every lane of the sub-group, then selected: a DPP move under a per-lane condition
+            // would read lanes that sit in the other branch
+            const v3 nx = mk3(sg8_next(P.x), sg8_next(P.y), sg8_next(P.z)), fx = mk3(sg8_bcast<0>(P.x), sg8_bcast<0>(P.y), sg8_bcast<0>(P.z));
+            const v3 b = mk3(wrap ? fx.x : nx.x, wrap ? fx.y : nx.y, wrap ? fx.z : nx.z);
             const float da = dot(P - pr, axis) - lim, db = dot(b - pr, axis) - lim;
             const bool have = sub < np;
             const int in = (have && da <= 0) ? 1 : 0, cr = (have && ((da < 0 && db > 0) || (da > 0 && db < 0))) ? 1 : 0;
             int incl = in + cr;
-#pragma unroll
-            for (int d = 1; d < 8; d <<= 1) { const int t = __shfl_up(incl, d, 8); if (sub >= d) incl += t; }
-            const int base = incl - in - cr, total = __shfl(incl, 7, 8);
+            { const int t1 = dppi_<0x111>(incl); if (sub >= 1) incl += t1;
+              const int t2 = dppi_<0x112>(incl); if (sub >= 2) incl += t2;
+              const int t4 = dppi_<0x114>(incl); if (sub >= 4) incl += t4; }
+            const int base = incl - in - cr, total = sg8_bcast<7>(incl);
             if (in && base < 8) { scr[3 * base] = P.x; scr[3 * base + 1] = P.y; scr[3 * base + 2] = P.z; }
             if (cr && base + in < 8) {
                 const float t = da * frcp(da - db);

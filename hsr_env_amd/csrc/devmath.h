@@ -1,6 +1,12 @@
 // Small fp32 vector helpers shared by the HIP kernels (device only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
+
+// compile-time unrolled loop: f(std::integral_constant<int, I>) for I in [I0, N)
+template <int I, int N, typename F> __device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
+}
 
 #define HSR_MINVAL 1e-15f
 #define HSR_MINIMP 0.0001f

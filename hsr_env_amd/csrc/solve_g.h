@@ -35,9 +35,6 @@ __device__ __forceinline__ unsigned long long stamp_() {
 #define PHASE(idx) do {} while (0)
 #define PHASE_FLUSH() do {} while (0)
 #endif
-template <int I, int N, typename F> __device__ __forceinline__ void static_for(F &&f) {
-    if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
-}
 // DPP controls (gfx90a+): row_shr:n = 0x110+n, row_ror:n = 0x120+n, row_newbcast:n = 0x150+n; a "row" is 16 lanes,
 // exactly one 16-lane env group, so these are single full-rate VALU modifiers instead of ds_bpermute round trips
 template <int CTRL, bool ZERO_OOB> __device__ __forceinline__ float dpp_f(float v) {
