@@ -72,6 +72,7 @@ __device__ __forceinline__ float impedance(const float *solimp, float pos) {
     if (x <= 0) return dmin;
     float y;
     if (power == 1.f) y = x;
+    else if (power == 2.f) y = x <= mid ? x * x * frcp(mid) : 1 - (1 - x) * (1 - x) * frcp(1 - mid);   // MuJoCo's default power: no powf
     else if (x <= mid) y = powf(x, power) / powf(mid, power - 1);
     else y = 1 - powf(1 - x, power) / powf(1 - mid, power - 1);
     return dmin + y * (dmax - dmin);
