@@ -179,7 +179,6 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(DevModel m, DevState s, i
                 const unsigned long long bal = __ballot(pass);
                 if (pass) sCand[ncand + __popcll(bal & ((1ull << tid) - 1ull))] = (unsigned short)((g << 14) | p);   // ncand < 64 here
                 ncand += __popcll(bal);
-                DBGCNT(1, __popcll(bal));
                 if (ncand >= 64) { __syncthreads(); box_round(); }
             }
             __syncthreads();

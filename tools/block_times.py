@@ -36,7 +36,7 @@ print('wave slot ids used:', np.unique(wv))
 life = en - st
 o = np.argsort(life)
 print('newton trips / substep: mean %.2f, slowest 10 blocks %s, fastest 10 %s' % (a[:, 4].mean() / 300, (a[o[-10:], 4] / 300).round(2), (a[o[:10], 4] / 300).round(2)))
-print('sphere-cull candidates / substep: mean %.2f, slowest 10 %s' % (a[:, 5].mean() / 300, (a[o[-10:], 5] / 300).round(2)))
+print('line-search iterations (env 0 of the workgroup) / substep: mean %.2f, slowest 10 %s' % (a[:, 5].mean() / 300, (a[o[-10:], 5] / 300).round(2)))
 print('narrowphase items / substep: mean %.2f, slowest 10 %s' % (a[:, 6].mean() / 300, (a[o[-10:], 6] / 300).round(2)))
 print('nefc sum / substep: mean %.2f, slowest 10 %s' % (a[:, 7].mean() / 300, (a[o[-10:], 7] / 300).round(2)))
 print('corr(life, newton) %.3f  corr(life, items) %.3f corr(life, nefc) %.3f' % (np.corrcoef(life, a[:, 4])[0, 1], np.corrcoef(life, a[:, 6])[0, 1], np.corrcoef(life, a[:, 7])[0, 1]))
