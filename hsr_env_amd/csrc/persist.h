@@ -60,7 +60,7 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(DevModel m, DevState s, i
     const bool isdof = c < nv;                                                                                               \
     (void)rD; (void)rAref; (void)rJar; (void)rJv; (void)rGr; (void)rDw; (void)kLin; (void)kAnc; (void)lk; (void)pcnt; (void)M; (void)con; \
     (void)xmatL; (void)qvelL; (void)poly; (void)isdof; (void)e; (void)in_range;
-    int bad_acc = 0;
+    int bad_acc = 0, trips_acc = 0;
     __shared__ int sParent[32], sMask[NLMAX], sDepth[NLMAX];
     __shared__ unsigned short sItems[64];
     __shared__ unsigned char sMpr[64];
@@ -89,6 +89,9 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(DevModel m, DevState s, i
     PHASE_T0();
 
     for (int sub = 0; sub < n_substeps; sub++) {
+        // a workgroup that carries a hard env (many Newton iterations per substep so far) sets the pace of the launch: it
+        // gets issue priority over the wave it shares its SIMD with, which has slack
+        if (sub >= 4 && 2 * trips_acc > 5 * sub) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);      // A/B on the bench: +4 %
         int tid_l = tid0;
         asm volatile("" : "+v"(tid_l));
         PERSIST_LANE_VIEW(tid_l)
@@ -335,6 +338,7 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(DevModel m, DevState s, i
                 if (bad) bad_acc = 1;
                 if (reach) done = true;          // a-4: latch; the env skips the remaining substeps
             }
+            trips_acc += newton_trips;
             __syncthreads();
             PHASE(18);
         }
