@@ -1,6 +1,6 @@
 """Diagnostic (CPU only): which contacts flicker in the envs that need many Newton iterations per substep."""
 import sys, numpy as np
-sys.path.insert(0, '.')
+sys.path.insert(0, '.')   # run from the repo root: python tests/diag/<name>.py
 from hsr_env_amd.compiler import load_config
 from bench import sample_inputs
 from oracle.oracle import OracleSim

@@ -1,6 +1,6 @@
 """Diagnostic: Newton iteration counts of the fp32 HIP solver vs the fp64 oracle on the hardest envs of the bench state."""
 import sys, numpy as np
-sys.path.insert(0, '.')
+sys.path.insert(0, '.')   # run from the repo root: python tests/diag/<name>.py
 from hsr_env_amd.compiler import load_config
 from hsr_env_amd import sim as hs
 from bench import sample_inputs
