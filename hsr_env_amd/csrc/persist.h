@@ -65,6 +65,10 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(DevModel m, DevState s, i
     __shared__ unsigned short sItems[64];
     __shared__ unsigned char sMpr[64];
     __shared__ unsigned short sCand[128];
+#ifdef HSR_PHASE_TIMING
+    __shared__ int sDbg[4];
+    if (tid0 < 4) sDbg[tid0] = 0;
+#endif
     __shared__ float sMass[NLMAX];
     if (tid0 < nv) sParent[tid0] = m.dof_parent[tid0];
     if (tid0 < m.nlink && tid0 < NLMAX) { sMask[tid0] = m.link_dofmask[tid0]; sMass[tid0] = m.link_mass[tid0]; sDepth[tid0] = m.link_depth[tid0]; }
@@ -236,6 +240,9 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(DevModel m, DevState s, i
                                 float depth; v3 dir, pos, sep;
                                 int nsup = 0;
                                 const bool hit = mpr_penetration<MW>(H1, H2, m.mpr_tolerance, m.mpr_iterations, depth, dir, pos, sep, nsup);
+#ifdef HSR_PHASE_TIMING
+                                if ((tid & (MW - 1)) == 0) { atomicAdd(&sDbg[0], nsup); atomicAdd(&sDbg[1], 1); atomicMax(&sDbg[2], nsup); }
+#endif
                                 if ((tid & (MW - 1)) == 0) {
                                     if (hit) { o2.add(pos, dir, -depth); sep = mk3(0, 0, 0); }
                                     sx[0] = sep.x; sx[N] = sep.y; sx[2 * (size_t)N] = sep.z;
@@ -355,6 +362,10 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(DevModel m, DevState s, i
             if (done) s.done[e] = 1;
         }
     }
+#ifdef HSR_PHASE_TIMING
+    __syncthreads();
+    dc_[1] = (unsigned long long)sDbg[0] | ((unsigned long long)sDbg[1] << 24) | ((unsigned long long)sDbg[2] << 48);
+#endif
     PHASE_FLUSH();
 #undef PERSIST_LANE_VIEW
 }

@@ -36,7 +36,9 @@ print('wave slot ids used:', np.unique(wv))
 life = en - st
 o = np.argsort(life)
 print('newton trips / substep: mean %.2f, slowest 10 blocks %s, fastest 10 %s' % (a[:, 4].mean() / 300, (a[o[-10:], 4] / 300).round(2), (a[o[:10], 4] / 300).round(2)))
-print('line-search iterations (env 0 of the workgroup) / substep: mean %.2f, slowest 10 %s' % (a[:, 5].mean() / 300, (a[o[-10:], 5] / 300).round(2)))
+nsup = a[:, 5] & 0xffffff; ncall = (a[:, 5] >> 24) & 0xffffff; nmax = a[:, 5] >> 48
+print('MPR runs / substep: mean %.2f, slowest 10 %s; supports per run: mean %.1f, slowest 10 %s; max supports in a run %d' % (
+    ncall.mean() / 300, (ncall[o[-10:]] / 300).round(2), nsup.sum() / max(ncall.sum(), 1), (nsup[o[-10:]] / np.maximum(ncall[o[-10:]], 1)).round(1), nmax.max()))
 print('narrowphase items / substep: mean %.2f, slowest 10 %s' % (a[:, 6].mean() / 300, (a[o[-10:], 6] / 300).round(2)))
 print('nefc sum / substep: mean %.2f, slowest 10 %s' % (a[:, 7].mean() / 300, (a[o[-10:], 7] / 300).round(2)))
 print('corr(life, newton) %.3f  corr(life, items) %.3f corr(life, nefc) %.3f' % (np.corrcoef(life, a[:, 4])[0, 1], np.corrcoef(life, a[:, 6])[0, 1], np.corrcoef(life, a[:, 7])[0, 1]))
