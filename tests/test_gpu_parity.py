@@ -322,3 +322,26 @@ def test_openai_observation_matches_numpy_restatement(models, cfg):
     err = np.abs(got - np.array(ref)).max(axis=1)
     assert (err < 2e-4).mean() >= 0.95, np.sort(err)[-6:]
     sim.close()
+
+
+@pytest.mark.parametrize("cfg", ["cfg3", "cfg4"])
+def test_ragged_batch_sizes(models, cfg):
+    """Batch sizes that do not fill the last workgroup (4 envs per wave at cfg3, 2 at cfg4) and the single-env case:
+    every env of a ragged batch gives bit-identical results to the same env inside a full batch."""
+    m = models[cfg]
+    rng = np.random.default_rng(41)
+    q, v, ctrl = random_states(m, 68, rng)
+    goal = np.column_stack([rng.uniform(-0.1, 0.1, 68), rng.uniform(-0.2, 0.2, 68), np.full(68, 0.422)])
+    bid = m.body_id(m.block_body())
+    full = hs.BatchSim(m, 68)
+    full.reset(qpos0=q, mocap=goal)
+    ref = full.step(ctrl, 40, bid, 0.03)
+    full.close()
+    for n in (1, 5, 67):
+        sim = hs.BatchSim(m, n)
+        sim.reset(qpos0=q[:n], mocap=goal[:n])
+        got = sim.step(ctrl[:n], 40, bid, 0.03)
+        for a, b in zip(got, ref):
+            assert np.array_equal(a, b[:n]), n
+        assert not sim.bad_state()[1]
+        sim.close()
