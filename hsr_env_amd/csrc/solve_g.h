@@ -43,42 +43,43 @@ template <int CTRL, bool ZERO_OOB> __device__ __forceinline__ float dpp_f(float 
     return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), CTRL, 0xf, 0xf, ZERO_OOB));
 }
 template <int CTRL, bool ZERO_OOB> __device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, ZERO_OOB); }
+// G = 32 (two envs per wave): a DPP row is 16 lanes, so the cross-row half of every group operation goes through
+// v_readlane (an SGPR per env, selected by the lane's env) instead of a ds_bpermute round trip through the LDS crossbar.
+// v_readlane reads its lane regardless of EXEC, which is what a group-uniform branch of one env needs.
+__device__ __forceinline__ int rl_(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+template <int L0, int L1> __device__ __forceinline__ int pick32_(int v) { const int a = rl_(v, L0), b = rl_(v, L1); return (threadIdx.x & 32) ? b : a; }
 // value of lane LANE of the group, in every lane of the group
 template <int G, int LANE> __device__ __forceinline__ float gbcast(float v) {
-    if constexpr (G == 16) return dpp_f<0x150 + LANE, true>(v); else return __shfl(v, LANE, G);
+    if constexpr (G == 16) return dpp_f<0x150 + LANE, true>(v);
+    else return __builtin_bit_cast(float, pick32_<LANE, 32 + LANE>(__builtin_bit_cast(int, v)));
 }
 template <int G> __device__ __forceinline__ float gsum(float v) {
-    if constexpr (G == 16) {
-        v += dpp_f<0x128, true>(v); v += dpp_f<0x124, true>(v); v += dpp_f<0x122, true>(v); v += dpp_f<0x121, true>(v);
-        return v;
-    } else {
-#pragma unroll
-        for (int off = G / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, G);
-        return v;
+    v += dpp_f<0x128, true>(v); v += dpp_f<0x124, true>(v); v += dpp_f<0x122, true>(v); v += dpp_f<0x121, true>(v);      // every lane: sum of its row
+    if constexpr (G == 16) return v;
+    else {
+        const int iv = __builtin_bit_cast(int, v);
+        const float lo = __builtin_bit_cast(float, pick32_<0, 32>(iv)), hi = __builtin_bit_cast(float, pick32_<16, 48>(iv));
+        return lo + hi;
     }
 }
 template <int G> __device__ __forceinline__ int gscan_incl(int v, int c) {
-    if constexpr (G == 16) {
-        v += dpp_i<0x111, true>(v); v += dpp_i<0x112, true>(v); v += dpp_i<0x114, true>(v); v += dpp_i<0x118, true>(v);
-        return v;
-    } else {
-#pragma unroll
-        for (int off = 1; off < G; off <<= 1) { const int t = __shfl_up(v, off, G); if (c >= off) v += t; }
-        return v;
-    }
+    v += dpp_i<0x111, true>(v); v += dpp_i<0x112, true>(v); v += dpp_i<0x114, true>(v); v += dpp_i<0x118, true>(v);      // inclusive scan inside the row
+    if constexpr (G == 16) return v;
+    else { const int first = pick32_<15, 47>(v); return (threadIdx.x & 16) ? v + first : v; }                                // second row: plus the total of the first
 }
 template <int G> __device__ __forceinline__ int gor(int v) {     // bitwise OR over the group, in every lane
-    if constexpr (G == 16) {
-        v |= dpp_i<0x128, true>(v); v |= dpp_i<0x124, true>(v); v |= dpp_i<0x122, true>(v); v |= dpp_i<0x121, true>(v);
-        return v;
-    } else {
-#pragma unroll
-        for (int off = G / 2; off > 0; off >>= 1) v |= __shfl_xor(v, off, G);
-        return v;
-    }
+    v |= dpp_i<0x128, true>(v); v |= dpp_i<0x124, true>(v); v |= dpp_i<0x122, true>(v); v |= dpp_i<0x121, true>(v);
+    if constexpr (G == 16) return v;
+    else return pick32_<0, 32>(v) | pick32_<16, 48>(v);
+}
+template <int G> __device__ __forceinline__ int gmax(int v) {    // maximum over the group, in every lane
+    { const int t = dpp_i<0x128, true>(v); v = t > v ? t : v; } { const int t = dpp_i<0x124, true>(v); v = t > v ? t : v; }
+    { const int t = dpp_i<0x122, true>(v); v = t > v ? t : v; } { const int t = dpp_i<0x121, true>(v); v = t > v ? t : v; }
+    if constexpr (G == 16) return v;
+    else { const int a = pick32_<0, 32>(v), b = pick32_<16, 48>(v); return a > b ? a : b; }
 }
 template <int G> __device__ __forceinline__ int glast(int v) {   // value of the last lane of the group
-    if constexpr (G == 16) return dpp_i<0x15F, false>(v); else return __shfl(v, G - 1, G);
+    if constexpr (G == 16) return dpp_i<0x15F, false>(v); else return pick32_<31, 63>(v);
 }
 
 // in-register cooperative Cholesky: lane c holds row c (entries k <= c) of an SPD matrix; on return row c of L in
