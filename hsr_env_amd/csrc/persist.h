@@ -114,15 +114,15 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(DevModel m, DevState s, i
             const KinLds K{lds + L.oKin + KINLDS_FLOATS * (mydepth > 0 ? c : 0)};   // this lane's link constants, read from LDS where they are used
             if (valid && c == 0) kin_link0(vx, vm, vd, w0, w1, w2, w3);
             __syncthreads();
+            // pose and velocity recursion of a link in the same visit: both need only the link's parent, done one level earlier
             for (int dlev = 1; dlev <= m.maxdepth; dlev++) {
-                if (valid && mydepth == dlev) kin_link_pose(K, c, vq, vx, vm, va, vl, vn);
+                if (valid && mydepth == dlev) {
+                    kin_link_pose(K, c, vq, vx, vm, va, vl, vn);
+                    kin_link_dyn(K, m.gravz, c, vv, vx, vm, va, vl, vn, vd, w0, w1, w2, w3);
+                }
                 __syncthreads();
             }
             PHASE(24);
-            for (int dlev = 1; dlev <= m.maxdepth; dlev++) {
-                if (valid && mydepth == dlev) kin_link_dyn(K, m.gravz, c, vv, vx, vm, va, vl, vn, vd, w0, w1, w2, w3);
-                __syncthreads();
-            }
         }
         PHASE(16);
         qpos_c = qposL[c];                                   // mj_kinematics normalises free-joint quaternions in place
