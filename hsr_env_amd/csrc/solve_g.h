@@ -53,6 +53,15 @@ template <int G, int LANE> __device__ __forceinline__ float gbcast(float v) {
     if constexpr (G == 16) return dpp_f<0x150 + LANE, true>(v);
     else return __builtin_bit_cast(float, pick32_<LANE, 32 + LANE>(__builtin_bit_cast(int, v)));
 }
+// acc += t * (value of lane LANE of the group of src): one v_fmac_f32_dpp.  LLVM forms v_fmac only after its DPP combine has
+// run on the VOP3 v_fma (no DPP encoding on gfx9), so the builtin form costs a v_mov_b32_dpp plus the fma.  The hand-written
+// form is invisible to the hazard recogniser: callers issue dpp_fence() (5 wait states: VALU write of the DPP source, VALU
+// write of EXEC) once before a run of these.
+__device__ __forceinline__ void dpp_fence() { asm volatile("s_nop 4"); }
+template <int G, int LANE> __device__ __forceinline__ void fmac_bcast(float &acc, float t, float src) {
+    if constexpr (G == 16) asm volatile("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(t), "n"(LANE));
+    else acc += t * gbcast<G, LANE>(src);
+}
 template <int G> __device__ __forceinline__ float gsum(float v) {
     v += dpp_f<0x128, true>(v); v += dpp_f<0x124, true>(v); v += dpp_f<0x122, true>(v); v += dpp_f<0x121, true>(v);      // every lane: sum of its row
     if constexpr (G == 16) return v;
