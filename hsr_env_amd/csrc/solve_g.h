@@ -107,9 +107,11 @@ template <int G, int NK = G> __device__ __forceinline__ bool chol_g(float (&row)
             if (c == j) invd = inv;
             row[j] = lcj;
             if (j < ndense) {
+                const float nl = -lcj;
+                dpp_fence();
                 static_for<j + 1, NK>([&](auto ic) {
                     constexpr int i = decltype(ic)::value;
-                    row[i] -= lcj * gbcast<G, i>(lcj);               // unconditional: entries i > c are never read
+                    fmac_bcast<G, i>(row[i], nl, lcj);               // row[i] -= lcj * L[i][j]; unconditional: entries i > c are never read
                 });
             }
         }
