@@ -32,25 +32,26 @@ template <int G> struct MfLayout {
 
 // tile-free triangular solves: lane c holds lo[k] = L[c][k] (k < c, else 0) and invd = 1 / L[c][c]
 template <int G, int NK = G> __device__ __forceinline__ float chol_solve_mf(const float (&row)[G], float invd, float b, int nv, int c) {
-    float lo[G];
+    float nlo[G];                                                // minus the strictly lower part of row c of L, 0 elsewhere
 #pragma unroll
-    for (int k = 0; k < NK; k++) lo[k] = (k < c) ? row[k] : 0.f;
+    for (int k = 0; k < NK; k++) nlo[k] = (k < c) ? -row[k] : 0.f;
     float sacc = b, y = 0.f;
     static_for<0, NK>([&](auto jc) {
         constexpr int j = decltype(jc)::value;
         if (j < nv) {
-            const float yj = gbcast<G, j>(sacc * invd);
-            if (c == j) y = yj;
-            sacc -= lo[j] * yj;
+            const float t = sacc * invd;                         // lane j: y_j
+            if (c == j) y = t;
+            asm volatile("s_nop 1");                             // VALU write of t -> DPP read
+            fmac_bcast<G, j>(sacc, nlo[j], t);                   // sacc -= L[c][j] y_j
         }
     });
-    // L^T x = y: x_j = (y_j - sum_{i > j} L[i][j] x_i) / L[j][j]; the sum runs over lanes (lo[j] is 0 for lanes i <= j)
+    // L^T x = y: x_j = (y_j - sum_{i > j} L[i][j] x_i) / L[j][j]; the sum runs over lanes (nlo[j] is 0 for lanes i <= j)
     float x = 0.f;
     static_for<0, NK>([&](auto jc) {
         constexpr int j = NK - 1 - decltype(jc)::value;
         if (j < nv) {
-            const float tot = gsum<G>(lo[j] * x);
-            if (c == j) x = (y - tot) * invd;
+            const float tot = gsum<G>(nlo[j] * x);
+            if (c == j) x = (y + tot) * invd;
         }
     });
     return x;
