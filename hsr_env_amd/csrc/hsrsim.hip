@@ -154,6 +154,7 @@ struct hsr_batch {
     int N = 0, device = 0;
     hipStream_t stream = nullptr;
     DevModel dm{};
+    DevModel *d_dm = nullptr;       // device copy for kernels that take the model by pointer
     DevState ds{};
     std::vector<void *> allocs;
     float *d_qpos0 = nullptr;      // model qpos0 on the device
@@ -178,7 +179,7 @@ struct hsr_batch {
 };
 
 // the persistent kernel instantiations: (lanes per env, compile-time bound on nv)
-typedef void (*persist_fn)(DevModel, DevState, int, int, float);
+typedef void (*persist_fn)(const DevModel *, DevState, int, int, float);
 static persist_fn persist_kernel(int group, int nv) {
     if (group == 16) return nv <= 8 ? k_env_step_mf<16, 8> : (nv <= 13 ? k_env_step_mf<16, 13> : k_env_step_mf<16, 16>);
     return nv <= 25 ? k_env_step_mf<32, 25> : k_env_step_mf<32, 32>;
@@ -725,7 +726,12 @@ extern "C" int hsr_batch_step_dev(hsr_batch *b, const float *d_ctrl, int n_subst
     if (b->persist && n_substeps > 0) {
         const int epb = 64 / b->group;
         if (b->profiling) { hipEvent_t ev; for (int k = 0; k < 3; k++) { hipEventCreate(&ev); hipEventRecord(ev, st); b->kev.push_back(ev); } }
-        hipLaunchKernelGGL(persist_kernel(b->group, b->dm.nv), dim3((N + epb - 1) / epb), dim3(64), b->persist_lds_bytes, st, b->dm, b->ds, n_substeps, goal_body, geofence);
+        if (!b->d_dm) {
+            int rc2 = dalloc(b, &b->d_dm, 1);
+            if (rc2) return rc2;
+            HIPCHK(hipMemcpy(b->d_dm, &b->dm, sizeof(DevModel), hipMemcpyHostToDevice));
+        }
+        hipLaunchKernelGGL(persist_kernel(b->group, b->dm.nv), dim3((N + epb - 1) / epb), dim3(64), b->persist_lds_bytes, st, (const DevModel *)b->d_dm, b->ds, n_substeps, goal_body, geofence);
         if (b->profiling) { hipEvent_t ev; hipEventCreate(&ev); hipEventRecord(ev, st); b->kev.push_back(ev); }   // slots 0,1 empty; slot 2 = the persistent kernel
     } else if (b->use_graph && !b->profiling && n_substeps > 0) {
         GraphKey key{n_substeps, goal_body, geofence};

@@ -34,7 +34,10 @@ template <int G> struct PersistLayout {
 
 // NVT: compile-time bound on nv (nv <= NVT <= G); the matrix loops of the solver run to NVT instead of G
 template <int G, int NVT>
-__global__ void __launch_bounds__(64, 2) k_env_step_mf(DevModel m, DevState s, int n_substeps, int goal_body, float geofence) {
+__global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restrict__ mp, DevState s, int n_substeps, int goal_body, float geofence) {
+    // the ~90 model fields stay in (constant-cached) memory and are read where they are used, instead of sitting in - and
+    // spilling from - SGPRs for the whole launch
+    const DevModel &m = *mp;
     extern __shared__ __align__(16) float lds[];
     constexpr int EPB = 64 / G, NK = NVT;
     const PersistLayout<G> L(m.njmax, s.kstride, m.npair_pad, m.nlink, m.ngeom);
