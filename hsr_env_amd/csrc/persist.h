@@ -33,7 +33,8 @@ template <int G> struct PersistLayout {
 };
 
 // NVT: compile-time bound on nv (nv <= NVT <= G); the matrix loops of the solver run to NVT instead of G
-template <int G, int NVT>
+// EXACT: nv == NVT, known at compile time (the `j < nv` guards of the unrolled matrix loops fold away)
+template <int G, int NVT, bool EXACT>
 __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restrict__ mp, DevState s, int n_substeps, int goal_body, float geofence) {
     // the ~90 model fields stay in (constant-cached) memory and are read where they are used, instead of sitting in - and
     // spilling from - SGPRs for the whole launch
@@ -42,7 +43,7 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
     constexpr int EPB = 64 / G, NK = NVT;
     const PersistLayout<G> L(m.njmax, s.kstride, m.npair_pad, m.nlink, m.ngeom);
     const int tid0 = threadIdx.x;
-    const int N = s.N, nv = m.nv, nq = m.nq, R = L.R, MS = L.MS;
+    const int N = s.N, nv = EXACT ? NVT : m.nv, nq = m.nq, R = L.R, MS = L.MS;
     const int mode = 1, debug = 0;
     // everything derived from the lane id is declared through this macro: once for the prologue, once per substep from a
     // laundered copy of the lane id (so that LLVM does not hoist ~100 loop-invariant addresses out of the substep loop and

@@ -55,12 +55,14 @@ template <int G, int LANE> __device__ __forceinline__ float gbcast(float v) {
 }
 // acc += t * (value of lane LANE of the group of src): one v_fmac_f32_dpp.  LLVM forms v_fmac only after its DPP combine has
 // run on the VOP3 v_fma (no DPP encoding on gfx9), so the builtin form costs a v_mov_b32_dpp plus the fma.  The hand-written
-// form is invisible to the hazard recogniser: callers issue dpp_fence() (5 wait states: VALU write of the DPP source, VALU
-// write of EXEC) once before a run of these.
-__device__ __forceinline__ void dpp_fence() { asm volatile("s_nop 4"); }
-template <int G, int LANE> __device__ __forceinline__ void fmac_bcast(float &acc, float t, float src) {
-    if constexpr (G == 16) asm volatile("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(t), "n"(LANE));
-    else acc += t * gbcast<G, LANE>(src);
+// form is invisible to the hazard recogniser and the scheduler may place the VALU instruction that produces src right in front
+// of it, so FIRST = true (the first use of a freshly computed src) carries the two wait states of the VALU-write -> DPP-read
+// hazard inside the same asm statement; later uses of the same src need none.
+template <int G, int LANE, bool FIRST = false> __device__ __forceinline__ void fmac_bcast(float &acc, float t, float src) {
+    if constexpr (G == 16) {
+        if constexpr (FIRST) asm volatile("s_nop 1\n\tv_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(t), "n"(LANE));
+        else asm volatile("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(t), "n"(LANE));
+    } else acc += t * gbcast<G, LANE>(src);
 }
 template <int G> __device__ __forceinline__ float gsum(float v) {
     v += dpp_f<0x128, true>(v); v += dpp_f<0x124, true>(v); v += dpp_f<0x122, true>(v); v += dpp_f<0x121, true>(v);      // every lane: sum of its row
@@ -108,10 +110,9 @@ template <int G, int NK = G> __device__ __forceinline__ bool chol_g(float (&row)
             row[j] = lcj;
             if (j < ndense) {
                 const float nl = -lcj;
-                dpp_fence();
                 static_for<j + 1, NK>([&](auto ic) {
                     constexpr int i = decltype(ic)::value;
-                    fmac_bcast<G, i>(row[i], nl, lcj);               // row[i] -= lcj * L[i][j]; unconditional: entries i > c are never read
+                    fmac_bcast<G, i, i == j + 1>(row[i], nl, lcj);   // row[i] -= lcj * L[i][j]; unconditional: entries i > c are never read
                 });
             }
         }
