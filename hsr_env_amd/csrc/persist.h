@@ -92,6 +92,29 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
         goal = mk3(s.mocap[e], s.mocap[N + e], s.mocap[2 * N + e]);
         time_e = s.time[e];
     }
+    // per-lane model constants of the solver: loaded once per launch (the registers are there since the exact-nv build)
+    float my_ctrl = 0, damp_c = 0;
+    int my_type = -1, my_qadr = 0, my_quat_lane = -1, my_limited = 0, my_act = -1;
+    float lim_lo = 0, lim_hi = 0, lim_sr0 = 1, lim_sr1 = 1, lim_iw = 0, lim_si[5] = {0, 0, 0, 0, 0};
+    float act_p[6] = {0, 0, 0, 0, 0, 0};
+    {
+        PERSIST_LANE_VIEW(tid0)
+        if (isdof) {
+            my_type = m.dof_type[c]; my_qadr = m.dof_qposadr[c]; my_limited = m.dof_limited[c]; my_act = m.dof_act[c];
+            my_quat_lane = m.link_dofadr[m.dof_link[c]] + 3;
+            damp_c = m.dof_damping[c];
+            lim_lo = m.dof_range[2 * c]; lim_hi = m.dof_range[2 * c + 1]; lim_sr0 = m.dof_solref[2 * c]; lim_sr1 = m.dof_solref[2 * c + 1];
+            lim_iw = m.dof_invweight0[c];
+#pragma unroll
+            for (int j = 0; j < 5; j++) lim_si[j] = m.dof_solimp[5 * c + j];
+            if (my_act >= 0) {
+                my_ctrl = s.ctrl[(size_t)my_act * N + e];
+                act_p[0] = m.act_kp[my_act]; act_p[1] = m.act_gear[my_act];
+                act_p[2] = m.act_ctrlrange[2 * my_act]; act_p[3] = m.act_ctrlrange[2 * my_act + 1];
+                act_p[4] = m.act_forcerange[2 * my_act]; act_p[5] = m.act_forcerange[2 * my_act + 1];
+            }
+        }
+    }
     const int goal_link = (goal_body >= 0 && !m.body_mocap[goal_body]) ? m.body_link[goal_body] : -1;
     const v3 goal_off = goal_body >= 0 ? ld3(m.body_pos, goal_body) : mk3(0, 0, 0);
     PHASE_T0();
@@ -286,26 +309,6 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
         int cnt_ch[MAXCH];
 #pragma unroll
         for (int ch = 0; ch < MAXCH; ch++) { const int p = ch * G + c; cnt_ch[ch] = (valid && p < m.npair) ? pcnt[p] : 0; }
-        // per-lane model constants are (re)loaded here, L2-resident, so that they are not live across the collision phase
-        float my_ctrl = 0, damp_c = 0;
-        int my_type = -1, my_qadr = 0, my_quat_lane = -1, my_limited = 0, my_act = -1;
-        float lim_lo = 0, lim_hi = 0, lim_sr0 = 1, lim_sr1 = 1, lim_iw = 0, lim_si[5] = {0, 0, 0, 0, 0};
-        float act_p[6] = {0, 0, 0, 0, 0, 0};
-        if (isdof) {
-            my_type = m.dof_type[c]; my_qadr = m.dof_qposadr[c]; my_limited = m.dof_limited[c]; my_act = m.dof_act[c];
-            my_quat_lane = m.link_dofadr[m.dof_link[c]] + 3;
-            damp_c = m.dof_damping[c];
-            lim_lo = m.dof_range[2 * c]; lim_hi = m.dof_range[2 * c + 1]; lim_sr0 = m.dof_solref[2 * c]; lim_sr1 = m.dof_solref[2 * c + 1];
-            lim_iw = m.dof_invweight0[c];
-#pragma unroll
-            for (int j = 0; j < 5; j++) lim_si[j] = m.dof_solimp[5 * c + j];
-            if (my_act >= 0) {
-                my_ctrl = s.ctrl[(size_t)my_act * N + e];
-                act_p[0] = m.act_kp[my_act]; act_p[1] = m.act_gear[my_act];
-                act_p[2] = m.act_ctrlrange[2 * my_act]; act_p[3] = m.act_ctrlrange[2 * my_act + 1];
-                act_p[4] = m.act_forcerange[2 * my_act]; act_p[5] = m.act_forcerange[2 * my_act + 1];
-            }
-        }
         // per-dof view of qpos (scalar joints: their own coordinate; free joints: lin dofs their coordinate)
         float my_q = 0;
         q4 quat0; quat0.w = 1; quat0.x = quat0.y = quat0.z = 0;
