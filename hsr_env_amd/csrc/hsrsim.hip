@@ -382,6 +382,7 @@ extern "C" int hsr_batch_create(const hsr_model *m, int n_envs, int device_id, h
     d.nq = sz[HSR_NQ]; d.nv = sz[HSR_NV]; d.nu = sz[HSR_NU]; d.nlink = sz[HSR_NLINK]; d.nbody = sz[HSR_NBODY];
     d.ngeom = sz[HSR_NGEOM]; d.npair = sz[HSR_NPAIR]; d.nslot = sz[HSR_NSLOT]; d.nconmax = sz[HSR_NCONMAX]; d.njmax = sz[HSR_NJMAX];
     if (d.npair > 384) return fail(HSR_EINVAL, "more than 384 candidate geom pairs");
+    if (d.ngeom > 255) return fail(HSR_EINVAL, "more than 255 geoms");
     d.nM = d.nv * (d.nv + 1) / 2;
     d.ndense = sz[13];
     d.timestep = (float)m->opt[0]; d.impratio = (float)m->opt[1]; d.gravz = (float)m->opt[2]; d.tolerance = (float)m->opt[3];
@@ -452,7 +453,7 @@ extern "C" int hsr_batch_create(const hsr_model *m, int n_envs, int device_id, h
         std::vector<float> rec((size_t)std::max(d.npair, 1) * 8, 0.f), grec((size_t)std::max(d.ngeom, 1) * 32, 0.f);
         for (int p = 0; p < d.npair; p++) {
             float *r = rec.data() + 8 * p;
-            r[0] = (float)g1[p]; r[1] = (float)g2[p]; r[2] = (float)gr[g1[p]]; r[3] = (float)gr[g2[p]];
+            r[0] = (float)(g1[p] + 256 * (gt[g1[p]] == GEOM_PLANE ? 1 : 0)); r[1] = (float)g2[p]; r[2] = (float)gr[g1[p]]; r[3] = (float)gr[g2[p]];   // [0]: geom1 | plane flag << 8
             r[4] = (float)fn[p]; r[5] = (float)sl[p]; r[6] = (float)(sl[p + 1] - sl[p]); r[7] = (float)gt[g1[p]];
         }
         for (int gg = 0; gg < d.ngeom; gg++) {

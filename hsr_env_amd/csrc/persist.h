@@ -189,7 +189,7 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
                     it = sCand[tid];
                     const float *gwi = lds + (size_t)(it >> 14) * L.envf + oGw;
                     const float4 a = pg4[2 * (it & 0x3fff)];
-                    const int g1 = (int)a.x, g2 = (int)a.y;
+                    const int g1 = (int)a.x & 255, g2 = (int)a.y;
                     pass = pair_cull_box(geom_cached(gwi + 16 * g1, m.geom_rec + 32 * g1, m.mesh_vert4), geom_cached(gwi + 16 * g2, m.geom_rec + 32 * g2, m.mesh_vert4), a.z, a.w);
                 }
                 const unsigned long long bal = __ballot(pass);
@@ -203,17 +203,26 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
                 __syncthreads();
                 ncand = rest;
             };
-            for (int p0 = 0; p0 < m.npair; p0 += G) {
-                const int p = p0 + c;
-                bool pass = false;
-                if (valid && p < m.npair) {
-                    const float4 a = pg4[2 * p];
-                    pass = pair_cull_sphere((int)m.pair_geo[8 * p + 7], gw + 16 * (int)a.x, gw + 16 * (int)a.y, a.z, a.w);
+            for (int pb = 0; pb < m.npair; pb += 8 * G) {
+                // the records of eight chunks of G pairs are fetched together (one round trip to L2, not eight) and tested;
+                // the compaction then walks the eight result bits
+                float4 a[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) { const int p = pb + u * G + c; a[u] = pg4[2 * (p < m.npair ? p : 0)]; }
+                unsigned int mybits = 0;
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const int p = pb + u * G + c, code = (int)a[u].x;
+                    if (valid && p < m.npair && pair_cull_sphere((code >> 8) ? GEOM_PLANE : GEOM_BOX, gw + 16 * (code & 255), gw + 16 * (int)a[u].y, a[u].z, a[u].w)) mybits |= 1u << u;
                 }
-                const unsigned long long bal = __ballot(pass);
-                if (pass) sCand[ncand + __popcll(bal & ((1ull << tid) - 1ull))] = (unsigned short)((g << 14) | p);   // ncand < 64 here
-                ncand += __popcll(bal);
-                if (ncand >= 64) { __syncthreads(); box_round(); }
+                for (int u = 0; u < 8 && pb + u * G < m.npair; u++) {
+                    const int p = pb + u * G + c;
+                    const bool pass = (mybits >> u) & 1u;
+                    const unsigned long long bal = __ballot(pass);
+                    if (pass) sCand[ncand + __popcll(bal & ((1ull << tid) - 1ull))] = (unsigned short)((g << 14) | p);   // ncand < 64 here
+                    ncand += __popcll(bal);
+                    if (ncand >= 64) { __syncthreads(); box_round(); }
+                }
             }
             __syncthreads();
             PHASE(19);
@@ -232,7 +241,7 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
                     const int ig = item >> 14, p = item & 0x3fff;
                     float *Ei = lds + (size_t)ig * L.envf;
                     const float4 pa = pg4[2 * p], pb = pg4[2 * p + 1];
-                    A = geom_cached(Ei + oGw + 16 * (int)pa.x, m.geom_rec + 32 * (int)pa.x, m.mesh_vert4);
+                    A = geom_cached(Ei + oGw + 16 * ((int)pa.x & 255), m.geom_rec + 32 * ((int)pa.x & 255), m.mesh_vert4);
                     B = geom_cached(Ei + oGw + 16 * (int)pa.y, m.geom_rec + 32 * (int)pa.y, m.mesh_vert4);
                     o.con = s.con + (size_t)(blockIdx.x * EPB + ig) * m.nslot * 8; o.slot = (int)pb.y; o.maxcnt = (int)pb.z; o.cnt = 0;
                     cntp = reinterpret_cast<unsigned char *>(Ei + L.oCnt) + p;
