@@ -6,10 +6,13 @@
 // (with per-substep kernels the mean workgroup lifetime was 110 us but the kernel lasted 244 us).
 //
 // Phases per substep and lane roles:
-//   K  kinematics + RNE recursion: lane 0 of the group walks the (<= 16-link) tree serially (kin_env, shared with k_kinematics)
-//   C  collision: lane = candidate pair (G pairs at a time): bounding culls, then box-box / plane / MPR narrowphase in the
-//      lanes whose pair survived; contacts go to the env's fixed (pair, index) slots, counts stay in LDS
-//   S  solve: the shared body of solve_mf.h (lane = dof / contact / row)
+//   K  kinematics + RNE recursion: lane = link, one tree level at a time (kin_link_pose / kin_link_dyn, shared with
+//      k_kinematics); the per-link constants come from a 52-float LDS record built once per launch
+//   C  collision: lane = geom places every geom once (LDS); lane = candidate pair of its env does the bounding-sphere cull
+//      (pair records of eight chunks fetched together); survivors of ALL envs of the workgroup are compacted with wave ballots
+//      and box-culled one per lane; the items that remain run the narrowphase side by side - one lane per plane item, one
+//      8-lane sub-group per MPR or box-box item; contacts go to the env's fixed (pair, index) slots, counts stay in LDS
+//   S  solve: the shared body solve_body.inc (lane = dof / contact / row), then the Euler update in registers
 #pragma once
 #include "collide.h"
 #include "solve_mf.h"
@@ -26,7 +29,7 @@ template <int G> struct PersistLayout {
         if (kin_tmp > b) b = kin_tmp;
         oB = (a + 3) & ~3;
         envf = (oB + b + 3) & ~3;
-        oPoly = envf * (64 / G);                                               // box-box polygon scratch: 4 slots of 48 floats per wave
+        oPoly = envf * (64 / G);                                               // box-box polygon scratch: 24 floats per 8-lane sub-group
         oKin = oPoly + 4 * 48;                                                 // per-link kinematic constants (KinLds), shared by the envs of the workgroup
         total = oKin + KINLDS_FLOATS * nlink;
     }
