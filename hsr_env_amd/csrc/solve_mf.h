@@ -1,7 +1,8 @@
 // Matrix-free cooperative solver kernel: same algorithm and lane-group geometry as solve_g.h (G lanes per env),
 // but the constraint Jacobian is never stored.  A contact row is  J[adr+j][c] = ax_j . P_c  (j < 3) or ax_{j-3} . Q_c
 // with P_c = sg_c (lin_c + ang_c x (pos - anchor_c)), Q_c = sg_c ang_c, so
-//   J v      = per contact: V = sum_c v_c P_c, W = sum_c v_c Q_c (six width-G DPP reductions), rows = ax . V, ax . W
+//   J v      = per DISTINCT link: its velocity field A + W x p under v (six width-G DPP reductions), then lane = contact:
+//              rows = ax . (V_l2(pos) - V_l1(pos)), ax . (W_l2 - W_l1)       (per contact when too many links are involved)
 //   J^T g    = per lane:    P_c . (g0 n + g1 t1 + g2 t2) + Q_c . (g3 n + g4 t1 + g5 t2)
 //   J^T w J  = per row: t = w * Jrc ; Hrow[k] += t * bcast_k(Jrc)   (DPP row_newbcast fused into the FMA)
 // Joint-limit rows (J = +-e_dof) live entirely in the registers of their dof lane.  nv-vectors (qacc, search, ...) are
