@@ -21,7 +21,7 @@ template <int G> struct PersistLayout {
     int R, MS, oRows, oCnt, oB, envf, oPoly, oKin, total;
     __host__ __device__ PersistLayout(int rows, int kstride, int npair_pad, int nlink, int ngeom) {
         R = rows; MS = G + 1;
-        int a = 6 * R > kstride ? 6 * R : kstride;                            // row scalars / kin record
+        int a = 5 * R > kstride ? 5 * R : kstride;                            // row scalars / kin record
         oRows = 0; oCnt = (a + 3) & ~3;                                       // pair counts survive phases A-D next to the kin record
         a = oCnt + (npair_pad + 3) / 4;                                        // one byte per pair
         int b = G * MS > C2_SIZE * G ? G * MS : C2_SIZE * G;                  // inertia matrix / contact records ...
@@ -57,7 +57,7 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
     const bool in_range = e_raw < N;                                                                                         \
     const int e = in_range ? e_raw : 0;                                                                                      \
     float *E = lds + (size_t)g * L.envf;                                                                                     \
-    float *rD = E + L.oRows, *rAref = rD + R, *rJar = rAref + R, *rJv = rJar + R, *rGr = rJv + R, *rDw = rGr + R;            \
+    float *rD = E + L.oRows, *rAref = rD + R, *rJar = rAref + R, *rJv = rJar + R, *rDw = rJv + R;            \
     float *kAng = E + L.oRows, *kLin = kAng + 3 * nv, *kAnc = kAng + 6 * nv, *lk = kAng + 9 * nv;                            \
     unsigned char *pcnt = reinterpret_cast<unsigned char *>(E + L.oCnt);                                                                       \
     float *M = E + L.oB, *con = E + L.oB;                                                                                    \
@@ -65,7 +65,7 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
     float *xposL = E + L.oB, *xmatL = xposL + 3 * m.nlink, *recL = xmatL + 9 * m.nlink, *qposL = recL + 12 * m.nlink, *qvelL = qposL + G; \
     float *poly = lds + L.oPoly;                                                                                             \
     const bool isdof = c < nv;                                                                                               \
-    (void)rD; (void)rAref; (void)rJar; (void)rJv; (void)rGr; (void)rDw; (void)kLin; (void)kAnc; (void)lk; (void)pcnt; (void)M; (void)con; \
+    (void)rD; (void)rAref; (void)rJar; (void)rJv; (void)rDw; (void)kLin; (void)kAnc; (void)lk; (void)pcnt; (void)M; (void)con; \
     (void)xmatL; (void)qvelL; (void)poly; (void)isdof; (void)e; (void)in_range;
     int bad_acc = 0, trips_acc = 0;
     __shared__ int sParent[32], sMask[NLMAX], sDepth[NLMAX];

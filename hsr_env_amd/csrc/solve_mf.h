@@ -23,7 +23,7 @@ template <int G> struct MfLayout {
     int R, MS, oRows, oB, oLv, total;
     __host__ __device__ MfLayout(int rows, int kstride) {
         R = rows; MS = G + 1;
-        const int a = 6 * R > kstride ? 6 * R : kstride;                    // row scalars; the kin record aliases them early on
+        const int a = 5 * R > kstride ? 5 * R : kstride;                    // row scalars; the kin record aliases them early on
         const int b = G * MS > C2_SIZE * G ? G * MS : C2_SIZE * G;          // inertia matrix, then contact records
         oRows = 0; oB = (a + 3) & ~3;
         oLv = (oB + b + 3) & ~3;                                            // per-link velocity fields of jmul: 5 links x 6
@@ -69,7 +69,7 @@ __global__ void __launch_bounds__(64, 2) k_solve_mf(DevModel m, DevState s, int 
     const int e = valid ? e_raw : 0;
     const int N = s.N, nv = m.nv, R = L.R, MS = L.MS;
     float *E = lds + (size_t)g * L.total;
-    float *rD = E + L.oRows, *rAref = rD + R, *rJar = rAref + R, *rJv = rJar + R, *rGr = rJv + R, *rDw = rGr + R;
+    float *rD = E + L.oRows, *rAref = rD + R, *rJar = rAref + R, *rJv = rJar + R, *rDw = rJv + R;
     float *kAng = E + L.oRows, *kLin = kAng + 3 * nv, *kAnc = kAng + 6 * nv, *lk = kAng + 9 * nv;     // kin_aos record (phases A-C)
     float *M = E + L.oB, *con = E + L.oB;
     float *lvbuf = E + L.oLv;
