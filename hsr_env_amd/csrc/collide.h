@@ -142,7 +142,7 @@ __device__ __forceinline__ void kin_link_pose(const KC &K, int l, View qpos, Vie
                 const v3 jp = K.dof_pos(k);
                 const v3 anchor = pos + mulmv(mat, jp);
                 float sn, cs;
-                sincosf(0.5f * q, &sn, &cs);
+                fast_sincos(0.5f * q, &sn, &cs);
                 q4 qr;
                 qr.w = cs; qr.x = ax.x * sn; qr.y = ax.y * sn; qr.z = ax.z * sn;
                 mat = mulmm(mat, q2m(qr));

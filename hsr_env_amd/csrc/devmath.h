@@ -19,6 +19,23 @@ __device__ __forceinline__ float frcp(float x) { return __builtin_amdgcn_rcpf(x)
 __device__ __forceinline__ float fsqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 __device__ __forceinline__ float frsq(float x) { return __builtin_amdgcn_rsqf(x); }
 
+// sin and cos for joint half-angles and integration steps (|x| of a few pi at most): one three-term Cody-Waite reduction to
+// [-pi/4, pi/4] and the Cephes single-precision minimax polynomials (1 ulp on the reduced range) - the library sincosf
+// carries a Payne-Hanek path for huge arguments that costs ~400 instructions of code at every call site
+__device__ __forceinline__ void fast_sincos(float x, float *sn, float *cs) {
+    const float k = rintf(x * 0.63661977236758134f);                       // x / (pi/2)
+    float r = fmaf(k, -1.5703125f, x);                                     // pi/2 in three pieces: 1e-7 absolute up to |x| ~ 20
+    r = fmaf(k, -4.837512969970703125e-4f, r);
+    r = fmaf(k, -7.54978995489188e-8f, r);
+    const float z = r * r;
+    const float ps = fmaf(fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f) * z, r, r);
+    const float pc = fmaf(fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f), z * z, fmaf(-0.5f, z, 1.0f));
+    const int q = (int)k & 3;
+    const float s0 = (q & 1) ? pc : ps, c0 = (q & 1) ? ps : pc;
+    *sn = (q & 2) ? -s0 : s0;
+    *cs = ((q + 1) & 2) ? -c0 : c0;
+}
+
 struct v3 { float x, y, z; };
 struct m3 { float a[9]; };   // row-major
 

@@ -348,7 +348,7 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
                     if (angle > 0) {
                         const v3 ax = w * (1.0f / wn);
                         float sn, cs;
-                        sincosf(0.5f * angle, &sn, &cs);
+                        fast_sincos(0.5f * angle, &sn, &cs);
                         q4 qr;
                         qr.w = cs; qr.x = ax.x * sn; qr.y = ax.y * sn; qr.z = ax.z * sn;
                         q = qnormalized(qmul(quat0, qr));
