@@ -317,10 +317,6 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
         __syncthreads();
         PHASE(17);
         // ---------------- S: dynamics + constraint solve + Euler (shared body)
-        constexpr int MAXCH = 384 / G;          // pair-count chunks of G pairs (npair <= 384, checked at batch creation)
-        int cnt_ch[MAXCH];
-#pragma unroll
-        for (int ch = 0; ch < MAXCH; ch++) { const int p = ch * G + c; cnt_ch[ch] = (valid && p < m.npair) ? pcnt[p] : 0; }
         // per-dof view of qpos (scalar joints: their own coordinate; free joints: lin dofs their coordinate)
         float my_q = 0;
         q4 quat0; quat0.w = 1; quat0.x = quat0.y = quat0.z = 0;
@@ -329,11 +325,13 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
             if (c == my_quat_lane && my_type == DOF_FREE_ANG) { quat0.w = qposL[my_qadr]; quat0.x = qposL[my_qadr + 1]; quat0.y = qposL[my_qadr + 2]; quat0.z = qposL[my_qadr + 3]; }
         }
         __syncthreads();             // qposL / link poses are read; region B may now be reused by the solver
-        float *lvbuf = reinterpret_cast<float *>(pcnt);       // the pair counts are in registers (cnt_ch): their LDS words are free
+        float *lvbuf = reinterpret_cast<float *>(pcnt);       // the pair counts are consumed by the contact compaction (E2), before the first J v
         const int lvcap = ((m.npair_pad + 3) / 4) / 6;
         {
 #define SOLVE_STORE_DIAG false
+#define PAIR_CNT(p) pcnt[p]
 #include "solve_body.inc"
+#undef PAIR_CNT
 #undef SOLVE_STORE_DIAG
             // ---------------- integrate (a-2.7) in registers; qpos is redistributed through LDS (lane = qpos index)
             const float v1 = __shfl_down(vnew, 1, G), v2 = __shfl_down(vnew, 2, G);

@@ -83,13 +83,7 @@ __global__ void __launch_bounds__(64, 2) k_solve_mf(DevModel m, DevState s, int 
 
     PHASE_T0();
     // ---------------- phase A: all first-level global loads, back to back
-    constexpr int MAXCH = 384 / G;          // pair-count chunks of G pairs (npair <= 384, checked at batch creation)
-    int cnt_ch[MAXCH];
-    {
-        const int *cp = s.ncon_pair + (size_t)e * m.npair_pad;
-#pragma unroll
-        for (int ch = 0; ch < MAXCH; ch++) { const int p = ch * G + c; cnt_ch[ch] = (valid && p < m.npair) ? cp[p] : 0; }
-    }
+    const int *pair_cnt_ = s.ncon_pair + (size_t)e * m.npair_pad;
     float qvel_c = 0, warm_c = 0, my_q = 0, my_ctrl = 0, damp_c = 0;
     int my_type = -1, my_qadr = 0, my_quat_lane = -1, my_limited = 0, my_act = -1;
     float lim_lo = 0, lim_hi = 0, lim_sr0 = 1, lim_sr1 = 1, lim_iw = 0, lim_si[5] = {0, 0, 0, 0, 0};
@@ -144,7 +138,9 @@ __global__ void __launch_bounds__(64, 2) k_solve_mf(DevModel m, DevState s, int 
         }
     }
 #define SOLVE_STORE_DIAG true
+#define PAIR_CNT(p) pair_cnt_[p]
 #include "solve_body.inc"
+#undef PAIR_CNT
 #undef SOLVE_STORE_DIAG
     const float v1 = __shfl_down(vnew, 1, G), v2 = __shfl_down(vnew, 2, G);
     PHASE(16);
