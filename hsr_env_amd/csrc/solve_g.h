@@ -64,6 +64,15 @@ template <int G, int LANE, bool FIRST = false> __device__ __forceinline__ void f
         else asm volatile("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(t), "n"(LANE));
     } else acc += t * gbcast<G, LANE>(src);
 }
+// group broadcast of a value that the preceding hand-written v_fmac_f32_dpp may have produced: the hazard recogniser cannot
+// see through inline asm, so this one carries its own wait states
+template <int G, int LANE> __device__ __forceinline__ float gbcast_after_asm(float v) {
+    if constexpr (G == 16) {
+        float r;
+        asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v), "n"(LANE));
+        return r;
+    } else return gbcast<G, LANE>(v);
+}
 template <int G> __device__ __forceinline__ float gsum(float v) {
     v += dpp_f<0x128, true>(v); v += dpp_f<0x124, true>(v); v += dpp_f<0x122, true>(v); v += dpp_f<0x121, true>(v);      // every lane: sum of its row
     if constexpr (G == 16) return v;
@@ -102,7 +111,7 @@ template <int G, int NK = G> __device__ __forceinline__ bool chol_g(float (&row)
     static_for<0, NK>([&](auto jc) {
         constexpr int j = decltype(jc)::value;
         if (j < nv) {
-            float ajj = gbcast<G, j>(row[j]);
+            float ajj = gbcast_after_asm<G, j>(row[j]);
             if (!(ajj >= HSR_MINVAL)) { ok = false; ajj = 1.f; }
             const float inv = __builtin_amdgcn_rsqf(ajj);            // 1 ulp; the factor only shapes a Newton / Euler solve
             const float lcj = row[j] * inv;                          // lane j: ajj * rsq(ajj) = sqrt(ajj)
