@@ -181,7 +181,7 @@ struct hsr_batch {
 // the persistent kernel instantiations: (lanes per env, compile-time bound on nv)
 typedef void (*persist_fn)(const DevModel *, DevState, int, int, float);
 static persist_fn persist_kernel(int group, int nv) {
-    if (group == 16) return nv == 8 ? k_env_step_mf<16, 8, true> : (nv == 13 ? k_env_step_mf<16, 13, true> : k_env_step_mf<16, 16, false>);
+    if (group == 16) return nv == 2 ? k_env_step_mf<16, 2, true> : (nv == 8 ? k_env_step_mf<16, 8, true> : (nv == 13 ? k_env_step_mf<16, 13, true> : k_env_step_mf<16, 16, false>));
     return nv == 25 ? k_env_step_mf<32, 25, true> : k_env_step_mf<32, 32, false>;
 }
 
