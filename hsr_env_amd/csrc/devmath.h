@@ -3,6 +3,15 @@
 #include <hip/hip_runtime.h>
 #include <type_traits>
 
+// Single-wave workgroups (64 threads): LDS operations of one wave are performed in issue order, so a "barrier" only has to
+// keep the compiler from moving memory operations across it - no s_barrier and, above all, no s_waitcnt vmcnt(0) on whatever
+// global stores / prefetches are in flight, which __syncthreads() implies.  Not for exchanging data through GLOBAL memory.
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+__device__ __forceinline__ bool wave_any(bool x) { return __ballot(x) != 0ull; }
+
 // compile-time unrolled loop: f(std::integral_constant<int, I>) for I in [I0, N)
 template <int I, int N, typename F> __device__ __forceinline__ void static_for(F &&f) {
     if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }

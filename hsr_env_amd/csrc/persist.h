@@ -130,12 +130,12 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
         asm volatile("" : "+v"(tid_l));
         PERSIST_LANE_VIEW(tid_l)
         const bool valid = !done;
-        if (!__syncthreads_or(valid)) break;
+        if (!wave_any(valid)) break;
         int bad = 0;                 // per substep; only a live env's flag is kept
         asm volatile("" ::: "memory");   // model constants are re-read (L2 hits) every substep instead of living in - and spilling from - registers
         // ---------------- K: kinematics of this env by lane 0 of its group, on LDS views
         qposL[c] = qpos_c; qvelL[c] = qvel_c;
-        __syncthreads();
+        wave_sync();
         {
             // lane = link, one tree level at a time (parents first); the per-link code is shared with k_kinematics
             const View vq{qposL, 1}, vv{qvelL, 1}, vx{xposL, 1}, vm{xmatL, 1}, va{kAng, 1}, vl{kLin, 1}, vn{kAnc, 1}, vd{lk, 1};
@@ -143,14 +143,14 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
             const int mydepth = (c < m.nlink && c < NLMAX) ? sDepth[c] : -1;
             const KinLds K{lds + L.oKin + KINLDS_FLOATS * (mydepth > 0 ? c : 0)};   // this lane's link constants, read from LDS where they are used
             if (valid && c == 0) kin_link0(vx, vm, vd, w0, w1, w2, w3);
-            __syncthreads();
+            wave_sync();
             // pose and velocity recursion of a link in the same visit: both need only the link's parent, done one level earlier
             for (int dlev = 1; dlev <= m.maxdepth; dlev++) {
                 if (valid && mydepth == dlev) {
                     kin_link_pose(K, c, vq, vx, vm, va, vl, vn);
                     kin_link_dyn(K, m.gravz, c, vv, vx, vm, va, vl, vn, vd, w0, w1, w2, w3);
                 }
-                __syncthreads();
+                wave_sync();
             }
             PHASE(24);
         }
@@ -180,7 +180,7 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
             const int oGw = (int)(gw - E);
             if (valid) for (int gi = c; gi < m.ngeom; gi += G) geom_place(m.geom_rec + 32 * gi, View{xposL, 1}, View{xmatL, 1}, gw + 16 * gi);
             for (int p0 = 0; p0 < m.npair_pad / 4; p0 += G) { const int p = p0 + c; if (p < m.npair_pad / 4) reinterpret_cast<int *>(pcnt)[p] = 0; }
-            __syncthreads();
+            wave_sync();
             const float4 *pg4 = reinterpret_cast<const float4 *>(m.pair_geo);
             int ncand = 0, nitems = 0;                             // wave-uniform
             // level 2 over the first min(ncand, 64) candidates of the list; the rest moves to the front
@@ -201,9 +201,9 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
                 const int rest = ncand - take;
                 unsigned short mv = 0;
                 if (tid < rest) mv = sCand[take + tid];
-                __syncthreads();
+                wave_sync();
                 if (tid < rest) sCand[tid] = mv;
-                __syncthreads();
+                wave_sync();
                 ncand = rest;
             };
             for (int pb = 0; pb < m.npair; pb += 8 * G) {
@@ -224,16 +224,16 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
                     const unsigned long long bal = __ballot(pass);
                     if (pass) sCand[ncand + __popcll(bal & ((1ull << tid) - 1ull))] = (unsigned short)((g << 14) | p);   // ncand < 64 here
                     ncand += __popcll(bal);
-                    if (ncand >= 64) { __syncthreads(); box_round(); }
+                    if (ncand >= 64) { wave_sync(); box_round(); }
                 }
             }
-            __syncthreads();
+            wave_sync();
             PHASE(19);
             while (ncand > 0) box_round();
             if (nitems > 64) bad = 1;                              // more than 64 surviving pairs in one workgroup: contacts would be dropped
             DBGCNT(2, nitems);
             if (nitems > 64) nitems = 64;
-            __syncthreads();
+            wave_sync();
             {
                 // every section rebuilds the geoms it needs from the placement cache, so that nothing but the item id
                 // stays live across the register-hungry narrowphases
@@ -264,7 +264,7 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
                     const unsigned long long cbal = __ballot(cv);
                     if (cv) sMpr[__popcll(cbal & ((1ull << tid) - 1ull))] = (unsigned char)tid;
                     const int ncv = __popcll(cbal);
-                    __syncthreads();
+                    wave_sync();
                     for (int r0 = 0; r0 < ncv; r0 += 64 / MW) {
                         const int k = r0 + tid / MW;
                         if (k < ncv) {
@@ -296,10 +296,10 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
                 {
                     const bool bb = fn == FN_BOX_BOX;
                     const unsigned long long bbal = __ballot(bb);
-                    __syncthreads();                                 // sMpr is reused as the box-box item list
+                    wave_sync();                                 // sMpr is reused as the box-box item list
                     if (bb) sMpr[__popcll(bbal & ((1ull << tid) - 1ull))] = (unsigned char)tid;
                     const int nbb = __popcll(bbal);
-                    __syncthreads();
+                    wave_sync();
                     for (int r0 = 0; r0 < nbb; r0 += 8) {
                         const int k = r0 + tid / 8;
                         if (k < nbb) {
@@ -324,7 +324,7 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
             my_q = qposL[my_qadr];
             if (c == my_quat_lane && my_type == DOF_FREE_ANG) { quat0.w = qposL[my_qadr]; quat0.x = qposL[my_qadr + 1]; quat0.y = qposL[my_qadr + 2]; quat0.z = qposL[my_qadr + 3]; }
         }
-        __syncthreads();             // qposL / link poses are read; region B may now be reused by the solver
+        wave_sync();             // qposL / link poses are read; region B may now be reused by the solver
         float *lvbuf = reinterpret_cast<float *>(pcnt);       // the pair counts are consumed by the contact compaction (E2), before the first J v
         const int lvcap = ((m.npair_pad + 3) / 4) / 6;
         {
@@ -335,7 +335,7 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
 #undef SOLVE_STORE_DIAG
             // ---------------- integrate (a-2.7) in registers; qpos is redistributed through LDS (lane = qpos index)
             const float v1 = __shfl_down(vnew, 1, G), v2 = __shfl_down(vnew, 2, G);
-            __syncthreads();
+            wave_sync();
             float *qn = rJv;             // any free row array: the solver is finished with it
             if (valid && isdof) {
                 if (my_type == DOF_SLIDE || my_type == DOF_HINGE || my_type == DOF_FREE_LIN) qn[my_qadr] = my_q + h * vnew;
@@ -354,7 +354,7 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
                     qn[my_qadr] = q.w; qn[my_qadr + 1] = q.x; qn[my_qadr + 2] = q.y; qn[my_qadr + 3] = q.z;
                 }
             }
-            __syncthreads();
+            wave_sync();
             if (valid) {
                 if (c < nq) qpos_c = qn[c];
                 qvel_c = vnew; warm_c = qacc_c;
@@ -363,7 +363,7 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
                 if (reach) done = true;          // a-4: latch; the env skips the remaining substeps
             }
             trips_acc += newton_trips;
-            __syncthreads();
+            wave_sync();
             PHASE(18);
         }
     }
@@ -380,7 +380,7 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
         }
     }
 #ifdef HSR_PHASE_TIMING
-    __syncthreads();
+    wave_sync();
     dc_[1] = (unsigned long long)sDbg[0] | ((unsigned long long)sDbg[1] << 24) | ((unsigned long long)sDbg[2] << 48);
 #endif
     PHASE_FLUSH();
