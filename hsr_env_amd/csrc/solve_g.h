@@ -58,12 +58,26 @@ template <int G, int LANE> __device__ __forceinline__ float gbcast(float v) {
 // form is invisible to the hazard recogniser and the scheduler may place the VALU instruction that produces src right in front
 // of it, so FIRST = true (the first use of a freshly computed src) carries the two wait states of the VALU-write -> DPP-read
 // hazard inside the same asm statement; later uses of the same src need none.
-template <int G, int LANE, bool FIRST = false> __device__ __forceinline__ void fmac_bcast(float &acc, float t, float src) {
-    if constexpr (G == 16) {
-        if constexpr (FIRST) asm volatile("s_nop 1\n\tv_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(t), "n"(LANE));
-        else asm volatile("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(t), "n"(LANE));
-    } else acc += t * gbcast<G, LANE>(src);
+// The broadcast source of a run of fmac_bcast.  G = 16: the value itself.  G = 32 (an env spans two DPP rows): one gfx950
+// v_permlane16_swap of the value with itself yields the two registers "first row of my group in both rows" and "second row
+// in both rows"; a row_newbcast on the right one then reaches any of the 32 lanes, so the whole run stays v_fmac_f32_dpp.
+template <int G> struct BcSrc { float lo, hi; };
+template <int G> __device__ __forceinline__ BcSrc<G> bc_prepare(float v) {
+    BcSrc<G> r;
+    if constexpr (G == 32) {
+        const unsigned u = __builtin_bit_cast(unsigned, v);
+        const auto sw = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+        r.lo = __builtin_bit_cast(float, (unsigned)sw[0]); r.hi = __builtin_bit_cast(float, (unsigned)sw[1]);
+    } else { r.lo = v; r.hi = v; }
+    return r;
 }
+template <int G, int LANE, bool FIRST = false> __device__ __forceinline__ void fmac_bcast(float &acc, float t, const BcSrc<G> &src) {
+    const float sv = (G == 32 && LANE >= 16) ? src.hi : src.lo;
+    if constexpr (FIRST) asm volatile("s_nop 1\n\tv_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(sv), "v"(t), "n"(LANE % 16));
+    else asm volatile("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(sv), "v"(t), "n"(LANE % 16));
+}
+// runs that cross lane 16 touch src.hi for the first time there: that use needs the wait states again (G = 32)
+template <int G, int LANE, int FIRST_LANE> constexpr bool bc_first() { return LANE == FIRST_LANE || (G == 32 && LANE == 16 && FIRST_LANE < 16); }
 // group broadcast of a value that the preceding hand-written v_fmac_f32_dpp may have produced: the hazard recogniser cannot
 // see through inline asm, so this one carries its own wait states
 template <int G, int LANE> __device__ __forceinline__ float gbcast_after_asm(float v) {
@@ -119,9 +133,10 @@ template <int G, int NK = G> __device__ __forceinline__ bool chol_g(float (&row)
             row[j] = lcj;
             if (j < ndense) {
                 const float nl = -lcj;
+                const BcSrc<G> bl = bc_prepare<G>(lcj);
                 static_for<j + 1, NK>([&](auto ic) {
                     constexpr int i = decltype(ic)::value;
-                    fmac_bcast<G, i, i == j + 1>(row[i], nl, lcj);   // row[i] -= lcj * L[i][j]; unconditional: entries i > c are never read
+                    fmac_bcast<G, i, bc_first<G, i, j + 1>()>(row[i], nl, bl);   // row[i] -= lcj * L[i][j]; unconditional: entries i > c are never read
                 });
             }
         }

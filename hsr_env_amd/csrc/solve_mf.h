@@ -42,7 +42,7 @@ template <int G, int NK = G> __device__ __forceinline__ float chol_solve_mf(cons
         if (j < nv) {
             const float t = sacc * invd;                         // lane j: y_j
             if (c == j) y = t;
-            fmac_bcast<G, j, true>(sacc, nlo[j], t);             // sacc -= L[c][j] y_j
+            fmac_bcast<G, j, true>(sacc, nlo[j], bc_prepare<G>(t));   // sacc -= L[c][j] y_j
         }
     });
     // L^T x = y: x_j = (y_j - sum_{i > j} L[i][j] x_i) / L[j][j]; the sum runs over lanes (nlo[j] is 0 for lanes i <= j)
