@@ -91,9 +91,9 @@ template <int G> __device__ __forceinline__ float gsum(float v) {
     v += dpp_f<0x128, true>(v); v += dpp_f<0x124, true>(v); v += dpp_f<0x122, true>(v); v += dpp_f<0x121, true>(v);      // every lane: sum of its row
     if constexpr (G == 16) return v;
     else {
-        const int iv = __builtin_bit_cast(int, v);
-        const float lo = __builtin_bit_cast(float, pick32_<0, 32>(iv)), hi = __builtin_bit_cast(float, pick32_<16, 48>(iv));
-        return lo + hi;
+        const unsigned u = __builtin_bit_cast(unsigned, v);
+        const auto sw = __builtin_amdgcn_permlane16_swap(u, u, false, false);      // [first row sum, second row sum] in every row of the group
+        return __builtin_bit_cast(float, (unsigned)sw[0]) + __builtin_bit_cast(float, (unsigned)sw[1]);
     }
 }
 template <int G> __device__ __forceinline__ int gscan_incl(int v, int c) {
@@ -104,13 +104,13 @@ template <int G> __device__ __forceinline__ int gscan_incl(int v, int c) {
 template <int G> __device__ __forceinline__ int gor(int v) {     // bitwise OR over the group, in every lane
     v |= dpp_i<0x128, true>(v); v |= dpp_i<0x124, true>(v); v |= dpp_i<0x122, true>(v); v |= dpp_i<0x121, true>(v);
     if constexpr (G == 16) return v;
-    else return pick32_<0, 32>(v) | pick32_<16, 48>(v);
+    else { const auto sw = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false); return (int)(sw[0] | sw[1]); }
 }
 template <int G> __device__ __forceinline__ int gmax(int v) {    // maximum over the group, in every lane
     { const int t = dpp_i<0x128, true>(v); v = t > v ? t : v; } { const int t = dpp_i<0x124, true>(v); v = t > v ? t : v; }
     { const int t = dpp_i<0x122, true>(v); v = t > v ? t : v; } { const int t = dpp_i<0x121, true>(v); v = t > v ? t : v; }
     if constexpr (G == 16) return v;
-    else { const int a = pick32_<0, 32>(v), b = pick32_<16, 48>(v); return a > b ? a : b; }
+    else { const auto sw = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false); const int a = (int)sw[0], b = (int)sw[1]; return a > b ? a : b; }
 }
 template <int G> __device__ __forceinline__ int glast(int v) {   // value of the last lane of the group
     if constexpr (G == 16) return dpp_i<0x15F, false>(v); else return pick32_<31, 63>(v);
