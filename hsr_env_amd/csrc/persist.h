@@ -15,6 +15,7 @@
 //   S  solve: the shared body solve_body.inc (lane = dof / contact / row), then the Euler update in registers
 #pragma once
 #include "collide.h"
+#include "kin2.h"
 #include "solve_mf.h"
 
 template <int G> struct PersistLayout {
@@ -25,13 +26,13 @@ template <int G> struct PersistLayout {
         oRows = 0; oCnt = (a + 3) & ~3;                                       // pair counts survive phases A-D next to the kin record
         a = oCnt + (npair_pad + 3) / 4;                                        // one byte per pair
         int b = G * MS > C2_SIZE * G ? G * MS : C2_SIZE * G;                  // inertia matrix / contact records ...
-        const int kin_tmp = 24 * nlink + 2 * G + 16 * ngeom;                   // ... or link poses + recursion scratch + qpos/qvel staging + geom placements
+        const int kin_tmp = 24 * nlink + 2 * G + (16 * ngeom > 8 * G ? 16 * ngeom : 8 * G);   // ... or link poses + local transforms + qpos/qvel staging + geom placements (dof velocity increments before them)
         if (kin_tmp > b) b = kin_tmp;
         oB = (a + 3) & ~3;
         envf = (oB + b + 3) & ~3;
         oPoly = envf * (64 / G);                                               // box-box polygon scratch: 24 floats per 8-lane sub-group
-        oKin = oPoly + 4 * 48;                                                 // per-link kinematic constants (KinLds), shared by the envs of the workgroup
-        total = oKin + KINLDS_FLOATS * nlink;
+        oKin = oPoly + 4 * 48;                                                 // per-link kinematic constants (kin2.h), shared by the envs of the workgroup
+        total = oKin + KIN2_FLOATS * nlink;
     }
 };
 
@@ -62,11 +63,11 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
     unsigned char *pcnt = reinterpret_cast<unsigned char *>(E + L.oCnt);                                                                       \
     float *M = E + L.oB, *con = E + L.oB;                                                                                    \
     /* kinematics scratch inside region B (dead before the solver writes M there) */                                        \
-    float *xposL = E + L.oB, *xmatL = xposL + 3 * m.nlink, *recL = xmatL + 9 * m.nlink, *qposL = recL + 12 * m.nlink, *qvelL = qposL + G; \
+    float *poseL = E + L.oB, *recL = poseL + 12 * m.nlink, *qposL = recL + 12 * m.nlink, *qvelL = qposL + G; \
     float *poly = lds + L.oPoly;                                                                                             \
     const bool isdof = c < nv;                                                                                               \
     (void)rD; (void)rAref; (void)rJar; (void)rJv; (void)rDw; (void)kLin; (void)kAnc; (void)lk; (void)pcnt; (void)M; (void)con; \
-    (void)xmatL; (void)qvelL; (void)poly; (void)isdof; (void)e; (void)in_range;
+    (void)poseL; (void)recL; (void)qvelL; (void)poly; (void)isdof; (void)e; (void)in_range;
     int bad_acc = 0, trips_acc = 0;
     __shared__ int sParent[32], sMask[NLMAX], sDepth[NLMAX];
     __shared__ unsigned short sItems[64];
@@ -79,7 +80,9 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
     __shared__ float sMass[NLMAX];
     if (tid0 < nv) sParent[tid0] = m.dof_parent[tid0];
     if (tid0 < m.nlink && tid0 < NLMAX) { sMask[tid0] = m.link_dofmask[tid0]; sMass[tid0] = m.link_mass[tid0]; sDepth[tid0] = m.link_depth[tid0]; }
-    if (tid0 < m.nlink) { KinLane K0; K0.load(m, tid0); kinlds_store(K0, lds + L.oKin + KINLDS_FLOATS * tid0); }
+    __shared__ unsigned char sDofLink[32];
+    if (tid0 < nv) sDofLink[tid0] = (unsigned char)m.dof_link[tid0];
+    if (tid0 < m.nlink) kin2_store(m, tid0, lds + L.oKin + KIN2_FLOATS * tid0);
 
     // ---------------- load the env state once; it lives in registers for the whole env-step
     float qpos_c = 0, qvel_c = 0, warm_c = 0;          // qpos_c: lane = qpos index; qvel_c / warm_c: lane = dof
@@ -133,42 +136,42 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
         if (!wave_any(valid)) break;
         int bad = 0;                 // per substep; only a live env's flag is kept
         asm volatile("" ::: "memory");   // model constants are re-read (L2 hits) every substep instead of living in - and spilling from - registers
-        // ---------------- K: kinematics of this env by lane 0 of its group, on LDS views
+        // ---------------- K: kinematics + RNE recursion (kin2.h): lane = link / dof, only the parent-dependent part per tree level
         qposL[c] = qpos_c; qvelL[c] = qvel_c;
         wave_sync();
         {
-            // lane = link, one tree level at a time (parents first); the per-link code is shared with k_kinematics
-            const View vq{qposL, 1}, vv{qvelL, 1}, vx{xposL, 1}, vm{xmatL, 1}, va{kAng, 1}, vl{kLin, 1}, vn{kAnc, 1}, vd{lk, 1};
-            const View w0{recL, 1}, w1{recL + 3 * m.nlink, 1}, w2{recL + 6 * m.nlink, 1}, w3{recL + 9 * m.nlink, 1};
-            const int mydepth = (c < m.nlink && c < NLMAX) ? sDepth[c] : -1;
-            const KinLds K{lds + L.oKin + KINLDS_FLOATS * (mydepth > 0 ? c : 0)};   // this lane's link constants, read from LDS where they are used
-            if (valid && c == 0) kin_link0(vx, vm, vd, w0, w1, w2, w3);
+            float *dwL = qvelL + G;                              // the geom placements are written after the kinematics
+            Kin2 kin;
+            kin.stageA(lds + L.oKin, m.nlink, c, qposL, recL);
             wave_sync();
-            // pose and velocity recursion of a link in the same visit: both need only the link's parent, done one level earlier
-            for (int dlev = 1; dlev <= m.maxdepth; dlev++) {
-                if (valid && mydepth == dlev) {
-                    kin_link_pose(K, c, vq, vx, vm, va, vl, vn);
-                    kin_link_dyn(K, m.gravz, c, vv, vx, vm, va, vl, vn, vd, w0, w1, w2, w3);
-                }
-                wave_sync();
-            }
-            PHASE(24);
+            PHASE(26);
+            kin.stageB(m.maxdepth, recL, poseL);
+            wave_sync();
+            PHASE(27);
+            kin.stageC(lds + L.oKin, sDofLink, nv, poseL, qvelL, kAng, kLin, kAnc, dwL);
+            wave_sync();
+            PHASE(28);
+            kin.stageD((c < m.nlink && c < NLMAX) ? sMask[c] : 0, qvelL, dwL, recL);
+            PHASE(29);
+            kin.stageE(m.gravz, lk);
+            wave_sync();
         }
+        PHASE(24);
         PHASE(16);
-        qpos_c = qposL[c];                                   // mj_kinematics normalises free-joint quaternions in place
+        if (valid) qpos_c = qposL[c];                        // mj_kinematics normalises free-joint quaternions in place
         if (!(fabsf(qpos_c) <= 1e10f) || !(fabsf(qvel_c) <= 1e10f)) bad = 1;
         // a-3 goal test uses the xpos of this substep's forward pass
         bool reach = false;
         if (goal_body >= 0) {
             v3 bp = goal;
-            if (goal_link >= 0) bp = mk3(xposL[3 * goal_link], xposL[3 * goal_link + 1], xposL[3 * goal_link + 2]) + mulmv(View{xmatL, 1}.getm(goal_link), goal_off);
+            if (goal_link >= 0) { m3 Rg; v3 pg; pose_load(poseL + 12 * goal_link, Rg, pg); bp = pg + mulmv(Rg, goal_off); }
             reach = norm(bp - goal) < geofence;
         }
         // link poses of an env's last substep go to global memory (sim.data.get_body_xpos after step(), hsr/env.py:144)
         if (valid && (sub == n_substeps - 1 || reach)) {
-            for (int i = c; i < 3 * m.nlink; i += G) s.xpos[(size_t)i * N + e] = xposL[i];
-            for (int i = c; i < 9 * m.nlink; i += G) s.xmat[(size_t)i * N + e] = xmatL[i];
-            for (int i = c; i < 6 * m.nlink; i += G) s.lvel[(size_t)i * N + e] = recL[i];       // link w, v(origin): first half of the recursion scratch
+            for (int i = c; i < 3 * m.nlink; i += G) s.xpos[(size_t)i * N + e] = poseL[12 * (i / 3) + 9 + i % 3];
+            for (int i = c; i < 9 * m.nlink; i += G) s.xmat[(size_t)i * N + e] = poseL[12 * (i / 9) + i % 9];
+            for (int i = c; i < 6 * m.nlink; i += G) { const int l = (i % (3 * m.nlink)) / 3; s.lvel[(size_t)i * N + e] = recL[12 * l + (i < 3 * m.nlink ? 0 : 3) + i % 3]; }   // link w, then v(origin)
         }
         // ---------------- C: collision
         // G: lane = geom, world placement of every geom once per substep (LDS, next to the link poses)
@@ -178,7 +181,7 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
         {
             float *gw = qvelL + G;
             const int oGw = (int)(gw - E);
-            if (valid) for (int gi = c; gi < m.ngeom; gi += G) geom_place(m.geom_rec + 32 * gi, View{xposL, 1}, View{xmatL, 1}, gw + 16 * gi);
+            if (valid) for (int gi = c; gi < m.ngeom; gi += G) geom_place2(m.geom_rec + 32 * gi, poseL, gw + 16 * gi);
             for (int p0 = 0; p0 < m.npair_pad / 4; p0 += G) { const int p = p0 + c; if (p < m.npair_pad / 4) reinterpret_cast<int *>(pcnt)[p] = 0; }
             wave_sync();
             const float4 *pg4 = reinterpret_cast<const float4 *>(m.pair_geo);

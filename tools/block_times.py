@@ -47,8 +47,8 @@ coef = np.linalg.lstsq(A, life * 300 / 300, rcond=None)[0]
 print('life us ~ %.0f + %.2f * newton_trips + %.2f * items + %.2f * nefc' % tuple(coef))
 
 names = ['A load', 'B/C M+bias', 'D chol M', 'E1-2', 'E3', 'E4-5', 'F0 warm', 'F grad', 'F hess', 'F chol', 'F ls loop', 'F eval', 'G(12)', 'F ls mv+sums(13)', 'exit+qfc(14)', 'G chol(15)',
-         'K kin(16)', 'C(17)', 'integrate(18)', 'C cull1(19)', 'C cull2(20)', 'C plane(21)', 'C mpr(22)', 'C boxbox(23)', 'K pose(24)', 'F ls jmul(25)']
-ph = a[:, 8:34].astype(np.float64) / 300.0
+         'K kin(16)', 'C(17)', 'integrate(18)', 'C cull1(19)', 'C cull2(20)', 'C plane(21)', 'C mpr(22)', 'C boxbox(23)', 'K pose(24)', 'F ls jmul(25)', 'x26', 'x27', 'x28', 'x29', 'x30', 'x31']
+ph = a[:, 8:40].astype(np.float64) / 300.0
 slow, med = o[-20:], o[nb // 2 - 10: nb // 2 + 10]
 print('phase cycles per substep: slowest 20 blocks vs 20 median blocks')
 for i, nm in enumerate(names):
