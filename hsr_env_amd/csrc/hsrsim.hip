@@ -170,6 +170,7 @@ struct hsr_batch {
     int group = 16;
     size_t group_lds_bytes = 0, mf_lds_bytes = 0, persist_lds_bytes = 0;
     bool persist = false;          // whole env-step in one persistent kernel (k_env_step_mf); HSR_PERSIST=0 disables
+    bool persist_ok = false;       // the model fits the persistent kernel (lane maps, LDS, kinematic structure): set once at creation
     bool use_graph = true, profiling = false;
     std::map<GraphKey, hipGraphExec_t> graphs;
     float last_total_ms = 0, last_kernel_ms[3] = {0, 0, 0};
@@ -424,6 +425,11 @@ extern "C" int hsr_batch_create(const hsr_model *m, int n_envs, int device_id, h
         const int *mn = m->i32("geom_meshnum");
         for (int g = 0; g < d.ngeom; g++) if (mn[g] > 256) return fail(HSR_EINVAL, "mesh hull with more than 256 vertices");
     }
+    {   // static geoms (world link) form a prefix of the geom list in every compiled model; anything else counts as moving
+        const int *gl = m->i32("geom_link");
+        d.nstatic_geom = 0;
+        while (d.nstatic_geom < d.ngeom && gl[d.nstatic_geom] == 0) d.nstatic_geom++;
+    }
     d.npair_pad = (d.npair + 31) & ~31;
     if (d.npair_pad == 0) d.npair_pad = 32;
     {   // derived tables: per-pair record and dof -> actuator map
@@ -457,13 +463,15 @@ extern "C" int hsr_batch_create(const hsr_model *m, int n_envs, int device_id, h
             r[4] = (float)fn[p]; r[5] = (float)sl[p]; r[6] = (float)(sl[p + 1] - sl[p]); r[7] = (float)gt[g1[p]];
         }
         for (int gg = 0; gg < d.ngeom; gg++) {
-            float *o = grec.data() + 32 * gg;
-            o[0] = (float)gl[gg]; o[1] = (float)gt[gg];
-            for (int k = 0; k < 3; k++) o[2 + k] = (float)gp[3 * gg + k];
-            quat2mat_h(gq + 4 * gg, o + 5);
-            for (int k = 0; k < 3; k++) o[14 + k] = (float)gs[3 * gg + k];
-            for (int k = 0; k < 6; k++) o[17 + k] = (float)gb[6 * gg + k];
-            o[23] = (float)mn[gg]; o[24] = (float)ma[gg]; o[25] = (float)gr[gg];
+            // seven float4: link type nvert meshadr | lpos rbound | lmat[0..3] | lmat[4..7] | lmat[8] size | aabb centre - | aabb half -
+            float *o = grec.data() + 32 * gg, lm[9];
+            quat2mat_h(gq + 4 * gg, lm);
+            o[0] = (float)gl[gg]; o[1] = (float)gt[gg]; o[2] = (float)mn[gg]; o[3] = (float)ma[gg];
+            for (int k = 0; k < 3; k++) o[4 + k] = (float)gp[3 * gg + k];
+            o[7] = (float)gr[gg];
+            for (int k = 0; k < 9; k++) o[8 + k] = lm[k];
+            for (int k = 0; k < 3; k++) o[17 + k] = (float)gs[3 * gg + k];
+            for (int k = 0; k < 3; k++) { o[20 + k] = (float)gb[6 * gg + k]; o[24 + k] = (float)gb[6 * gg + 3 + k]; }
         }
         float *dg; if ((rc = dalloc(b, &dg, rec.size()))) return rc;
         HIPCHK(hipMemcpy(dg, rec.data(), rec.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -539,18 +547,25 @@ extern "C" int hsr_batch_create(const hsr_model *m, int n_envs, int device_id, h
         }
     }
     if (b->solver == 2) {
-        const char *pe = getenv("HSR_PERSIST");
-        b->persist = !(pe && strcmp(pe, "0") == 0);
-        const int total = b->group == 16 ? PersistLayout<16>(d.njmax, b->ds.kstride, d.npair_pad, d.nlink, d.ngeom).total : PersistLayout<32>(d.njmax, b->ds.kstride, d.npair_pad, d.nlink, d.ngeom).total;
+        const int total = b->group == 16 ? PersistLayout<16>(d.njmax, b->ds.kstride, d.npair_pad, d.nlink, d.ngeom, d.nstatic_geom).total : PersistLayout<32>(d.njmax, b->ds.kstride, d.npair_pad, d.nlink, d.ngeom, d.nstatic_geom).total;
         b->persist_lds_bytes = (size_t)total * sizeof(float);
-        {   // KinLane preloads at most three scalar joints per body
-            const int *dn = m->i32("link_dofnum"), *lf = m->i32("link_free");
-            for (int l = 1; l < d.nlink; l++) if (!lf[l] && dn[l] > 3) b->persist = false;
+        // what the persistent kernel's lane maps and kinematics assume (kin2.h, persist.h); a model outside it runs the per-substep chain
+        bool ok = d.nq <= b->group && d.nv <= b->group && d.nlink <= b->group && d.nlink <= NLMAX && d.ngeom <= 64 && d.npair < (1 << 14) && d.maxdepth <= 9;
+        {
+            const int *dn = m->i32("link_dofnum"), *lf = m->i32("link_free"), *lp = m->i32("link_parent"), *gl = m->i32("geom_link");
+            for (int l = 1; l < d.nlink; l++) {
+                if (!lf[l] && dn[l] > 3) ok = false;                          // at most three scalar joints per link record
+                if (lf[l] && lp[l] != 0) ok = false;                          // free bodies hang off the world ...
+                if (lf[lp[l]]) ok = false;                                    // ... and carry no children
+            }
+            for (int gi = d.nstatic_geom; gi < d.ngeom; gi++) if (gl[gi] == 0) ok = false;   // static geoms form a prefix of the geom list
         }
-        if (b->persist_lds_bytes > 160 * 1024) b->persist = false;
-        else if (b->persist_lds_bytes > 48 * 1024) {
+        if (b->persist_lds_bytes > 160 * 1024) ok = false;
+        b->persist_ok = ok;
+        const char *pe = getenv("HSR_PERSIST");
+        b->persist = ok && !(pe && strcmp(pe, "0") == 0);
+        if (ok && b->persist_lds_bytes > 48 * 1024)
             HIPCHK(hipFuncSetAttribute((const void *)persist_kernel(b->group, d.nv), hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->persist_lds_bytes));
-        }
     }
     if (getenv("HSR_DEBUG")) {
         int nb = -1;
@@ -608,7 +623,7 @@ extern "C" void *hsr_batch_stream(const hsr_batch *b) { return (void *)b->stream
 extern "C" int hsr_batch_sync(hsr_batch *b) { HIPCHK(hipSetDevice(b->device)); HIPCHK(hipStreamSynchronize(b->stream)); return HSR_OK; }
 extern "C" int hsr_batch_set_profiling(hsr_batch *b, int on) { b->profiling = on != 0; return HSR_OK; }
 extern "C" int hsr_batch_set_graph(hsr_batch *b, int on) { b->use_graph = on != 0; return HSR_OK; }
-extern "C" int hsr_batch_set_persistent(hsr_batch *b, int on) { b->persist = on != 0 && b->solver == 2 && b->persist_lds_bytes > 0 && b->persist_lds_bytes <= 160 * 1024; return b->persist ? 1 : 0; }
+extern "C" int hsr_batch_set_persistent(hsr_batch *b, int on) { b->persist = on != 0 && b->persist_ok; return b->persist ? 1 : 0; }
 extern "C" int hsr_batch_is_persistent(const hsr_batch *b) { return b->persist ? 1 : 0; }
 
 // one substep = 3 launches on the batch stream

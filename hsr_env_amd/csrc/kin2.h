@@ -199,17 +199,65 @@ struct Kin2 {
 };
 
 
-// world placement of geom gi (16 floats: pos3 mat9 box-centre3 -) from the link pose records; rec = DevModel::geom_rec + 32 gi
-__device__ __forceinline__ void geom_place2(const float *rec, const float *poseL, float *out) {
-    const int l = (int)rec[0];
-    m3 R, lm;
-    v3 pl;
-    pose_load(poseL + 12 * l, R, pl);
-#pragma unroll
-    for (int k = 0; k < 9; k++) lm.a[k] = rec[5 + k];
-    const v3 pos = pl + mulmv(R, mk3(rec[2], rec[3], rec[4]));
+// Geom cache of the persistent kernel.  World placement of a geom = 16 floats (pos3 mat9, then the box centre - or, for a
+// plane, its normal): static geoms (link 0, a prefix of the geom list) are placed once per launch into a table shared by the
+// envs of the workgroup, moving geoms once per substep into their env's LDS.  The constants the culls / narrowphases need
+// (8 floats per geom: size3, type | nvert << 4 | meshadr << 13; box half extents3, bounding radius) live in a second shared
+// table, so that nothing of the collision front end goes to global memory but the prefetched placement constants.
+struct GeomPlaceC { float4 q1, q2, q3, q4, q5; int link, type; };     // lpos | lmat[0..3] | lmat[4..7] | lmat[8] size | aabb centre
+__device__ __forceinline__ GeomPlaceC geom_place_consts(const float *rec) {
+    const float4 *r4 = reinterpret_cast<const float4 *>(rec);
+    GeomPlaceC k;
+    const float4 q0 = r4[0];
+    k.q1 = r4[1]; k.q2 = r4[2]; k.q3 = r4[3]; k.q4 = r4[4]; k.q5 = r4[5];
+    k.link = (int)q0.x; k.type = (int)q0.y;
+    return k;
+}
+__device__ __forceinline__ void geom_place3(const GeomPlaceC &k, const m3 &R, v3 pl, float *out) {
+    m3 lm;
+    lm.a[0] = k.q2.x; lm.a[1] = k.q2.y; lm.a[2] = k.q2.z; lm.a[3] = k.q2.w; lm.a[4] = k.q3.x; lm.a[5] = k.q3.y; lm.a[6] = k.q3.z; lm.a[7] = k.q3.w; lm.a[8] = k.q4.x;
+    const v3 pos = pl + mulmv(R, mk3(k.q1.x, k.q1.y, k.q1.z));
     const m3 mat = mulmm(R, lm);
-    const v3 bc = pos + mulmv(mat, mk3(rec[17], rec[18], rec[19]));
+    v3 bc = pos + mulmv(mat, mk3(k.q5.x, k.q5.y, k.q5.z));
+    if (k.type == GEOM_PLANE) bc = col(mat, 2);
     ks4(out, make_float4(pos.x, pos.y, pos.z, mat.a[0])); ks4(out + 4, make_float4(mat.a[1], mat.a[2], mat.a[3], mat.a[4]));
     ks4(out + 8, make_float4(mat.a[5], mat.a[6], mat.a[7], mat.a[8])); ks4(out + 12, make_float4(bc.x, bc.y, bc.z, 0.f));
 }
+__device__ __forceinline__ void geom_consts_store(const float *rec, float *out) {
+    const float4 *r4 = reinterpret_cast<const float4 *>(rec);
+    const float4 q0 = r4[0], q1 = r4[1], q4 = r4[4], q6 = r4[6];
+    const unsigned pk = (unsigned)(int)q0.y | ((unsigned)(int)q0.z << 4) | ((unsigned)(int)q0.w << 13);
+    ks4(out, make_float4(q4.y, q4.z, q4.w, __uint_as_float(pk))); ks4(out + 4, make_float4(q6.x, q6.y, q6.z, q1.w));
+}
+// Geom from its cached world placement w (16 floats) and its constants cc (8 floats), both in LDS
+__device__ __forceinline__ Geom geom_cached3(const float *w, const float *cc, const float4 *mesh_vert4, float &rbound) {
+    const float4 w0 = kl4(w), w1 = kl4(w + 4), w2 = kl4(w + 8), w3 = kl4(w + 12), c0 = kl4(cc), c1 = kl4(cc + 4);
+    Geom G;
+    G.pos = mk3(w0.x, w0.y, w0.z);
+    G.mat.a[0] = w0.w; G.mat.a[1] = w1.x; G.mat.a[2] = w1.y; G.mat.a[3] = w1.z; G.mat.a[4] = w1.w; G.mat.a[5] = w2.x; G.mat.a[6] = w2.y; G.mat.a[7] = w2.z; G.mat.a[8] = w2.w;
+    G.bc = mk3(w3.x, w3.y, w3.z);
+    const unsigned pk = __float_as_uint(c0.w);
+    G.type = pk & 15;
+    G.size = mk3(c0.x, c0.y, c0.z);
+    G.bh = mk3(c1.x, c1.y, c1.z);
+    G.nvert = (pk >> 4) & 511;
+    G.verts = mesh_vert4 + (pk >> 13);
+    rbound = c1.w;
+    return G;
+}
+// the oriented-box cull of pair_cull_box (collide.h) without data-dependent branches: both arms are evaluated and selected
+__device__ __forceinline__ bool pair_cull_box_nb(const Geom &G1, const Geom &G2, float rb1, float rb2) {
+    const v3 n = col(G1.mat, 2);
+    const bool plane_pass = dot(G2.bc - G1.pos, n) - (fabsf(dot(n, col(G2.mat, 0))) * G2.bh.x + fabsf(dot(n, col(G2.mat, 1))) * G2.bh.y + fabsf(dot(n, col(G2.mat, 2))) * G2.bh.z) <= 0.f;
+    const bool s1 = sphere_hits_obb(G2.pos, rb2, G1), s2 = sphere_hits_obb(G1.pos, rb1, G2), ov = obb_overlap(G1, G2);
+    return G1.type == GEOM_PLANE ? plane_pass : (s1 & s2 & ov);
+}
+// sphere-cull record of a candidate pair, one dword: geom1 (6 bits) | geom2 (6 bits) | narrowphase function (2 bits; 0 and 1 mean
+// geom1 is a plane) | - | upper half of the fp32 radius bound (sum of the bounding radii; geom2's alone against a plane), rounded
+// up: a slightly larger bound only passes a few more candidates on to the oriented-box cull
+__device__ __forceinline__ unsigned pair_pack(int g1, int g2, int fn, float rad) {
+    return (unsigned)g1 | ((unsigned)g2 << 6) | ((unsigned)fn << 12) | (((__float_as_uint(rad) + 0xffffu) >> 16) << 16);
+}
+__device__ __forceinline__ int pk_g1(unsigned pk) { return pk & 63; }
+__device__ __forceinline__ int pk_g2(unsigned pk) { return (pk >> 6) & 63; }
+__device__ __forceinline__ int pk_fn(unsigned pk) { return (pk >> 12) & 3; }

@@ -19,20 +19,24 @@
 #include "solve_mf.h"
 
 template <int G> struct PersistLayout {
-    int R, MS, oRows, oCnt, oB, envf, oPoly, oKin, total;
-    __host__ __device__ PersistLayout(int rows, int kstride, int npair_pad, int nlink, int ngeom) {
+    int R, MS, oRows, oCnt, oB, envf, oPoly, oKin, oPair, oGeomC, oGeomS, total;
+    __host__ __device__ PersistLayout(int rows, int kstride, int npair_pad, int nlink, int ngeom, int nstatic) {
         R = rows; MS = G + 1;
         int a = 5 * R > kstride ? 5 * R : kstride;                            // row scalars / kin record
         oRows = 0; oCnt = (a + 3) & ~3;                                       // pair counts survive phases A-D next to the kin record
         a = oCnt + (npair_pad + 3) / 4;                                        // one byte per pair
         int b = G * MS > C2_SIZE * G ? G * MS : C2_SIZE * G;                  // inertia matrix / contact records ...
-        const int kin_tmp = 24 * nlink + 2 * G + (16 * ngeom > 8 * G ? 16 * ngeom : 8 * G);   // ... or link poses + local transforms + qpos/qvel staging + geom placements (dof velocity increments before them)
+        const int nmov = ngeom - nstatic;
+        const int kin_tmp = 24 * nlink + 2 * G + (16 * nmov > 8 * G ? 16 * nmov : 8 * G);   // ... or link poses + local transforms + qpos/qvel staging + moving-geom placements (dof velocity increments before them)
         if (kin_tmp > b) b = kin_tmp;
         oB = (a + 3) & ~3;
         envf = (oB + b + 3) & ~3;
         oPoly = envf * (64 / G);                                               // box-box polygon scratch: 24 floats per 8-lane sub-group
         oKin = oPoly + 4 * 48;                                                 // per-link kinematic constants (kin2.h), shared by the envs of the workgroup
-        total = oKin + KIN2_FLOATS * nlink;
+        oPair = oKin + KIN2_FLOATS * nlink;                                     // packed sphere-cull record per candidate pair (one dword), rows of 8
+        oGeomC = oPair + ((npair_pad + 7) & ~7);                                // narrowphase constants of every geom (8 floats each)
+        oGeomS = oGeomC + 8 * ngeom;                                            // world placements of the static geoms (16 floats each)
+        total = oGeomS + 16 * nstatic;
     }
 };
 
@@ -45,7 +49,7 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
     const DevModel &m = *mp;
     extern __shared__ __align__(16) float lds[];
     constexpr int EPB = 64 / G, NK = NVT;
-    const PersistLayout<G> L(m.njmax, s.kstride, m.npair_pad, m.nlink, m.ngeom);
+    const PersistLayout<G> L(m.njmax, s.kstride, m.npair_pad, m.nlink, m.ngeom, m.nstatic_geom);
     const int tid0 = threadIdx.x;
     const int N = s.N, nv = EXACT ? NVT : m.nv, nq = m.nq, R = L.R, MS = L.MS;
     const int mode = 1, debug = 0;
@@ -69,20 +73,39 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
     (void)rD; (void)rAref; (void)rJar; (void)rJv; (void)rDw; (void)kLin; (void)kAnc; (void)lk; (void)pcnt; (void)M; (void)con; \
     (void)poseL; (void)recL; (void)qvelL; (void)poly; (void)isdof; (void)e; (void)in_range;
     int bad_acc = 0, trips_acc = 0;
-    __shared__ int sParent[32], sMask[NLMAX], sDepth[NLMAX];
-    __shared__ unsigned short sItems[64];
+    __shared__ int sParent[32], sMask[NLMAX];
+    __shared__ unsigned short sItems[64 * (64 / G)];   // narrowphase work items: at most 64 per env, processed 64 at a time
     __shared__ unsigned char sMpr[64];
-    __shared__ unsigned short sCand[128];
 #ifdef HSR_PHASE_TIMING
     __shared__ int sDbg[4];
     if (tid0 < 4) sDbg[tid0] = 0;
 #endif
     __shared__ float sMass[NLMAX];
     if (tid0 < nv) sParent[tid0] = m.dof_parent[tid0];
-    if (tid0 < m.nlink && tid0 < NLMAX) { sMask[tid0] = m.link_dofmask[tid0]; sMass[tid0] = m.link_mass[tid0]; sDepth[tid0] = m.link_depth[tid0]; }
+    if (tid0 < m.nlink && tid0 < NLMAX) { sMask[tid0] = m.link_dofmask[tid0]; sMass[tid0] = m.link_mass[tid0]; }
     __shared__ unsigned char sDofLink[32];
     if (tid0 < nv) sDofLink[tid0] = (unsigned char)m.dof_link[tid0];
     if (tid0 < m.nlink) kin2_store(m, tid0, lds + L.oKin + KIN2_FLOATS * tid0);
+    // geom cache: constants of every geom, placements of the static ones (world link: identity pose)
+    for (int gi = tid0; gi < m.ngeom; gi += 64) {
+        geom_consts_store(m.geom_rec + 32 * gi, lds + L.oGeomC + 8 * gi);
+        if (gi < m.nstatic_geom) {
+            m3 I3;
+#pragma unroll
+            for (int k = 0; k < 9; k++) I3.a[k] = (k % 4 == 0) ? 1.f : 0.f;
+            geom_place3(geom_place_consts(m.geom_rec + 32 * gi), I3, mk3(0, 0, 0), lds + L.oGeomS + 16 * gi);
+        }
+    }
+    // sphere-cull records of the candidate pairs (kin2.h: pair_pack)
+    for (int p = tid0; p < ((m.npair_pad + 7) & ~7); p += 64) {
+        unsigned pk = 0;
+        if (p < m.npair) {
+            const float4 a = reinterpret_cast<const float4 *>(m.pair_geo)[2 * p], b = reinterpret_cast<const float4 *>(m.pair_geo)[2 * p + 1];
+            const int code = (int)a.x;
+            pk = pair_pack(code & 255, (int)a.y, (int)b.x, (code >> 8) ? a.w : a.z + a.w);
+        }
+        reinterpret_cast<unsigned *>(lds + L.oPair)[p] = pk;
+    }
 
     // ---------------- load the env state once; it lives in registers for the whole env-step
     float qpos_c = 0, qvel_c = 0, warm_c = 0;          // qpos_c: lane = qpos index; qvel_c / warm_c: lane = dof
@@ -136,6 +159,9 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
         if (!wave_any(valid)) break;
         int bad = 0;                 // per substep; only a live env's flag is kept
         asm volatile("" ::: "memory");   // model constants are re-read (L2 hits) every substep instead of living in - and spilling from - registers
+        // placement constants of this lane's moving geom: fetched now, consumed after the kinematics (the L2 latency hides behind it)
+        const int nstat = m.nstatic_geom, nmov = m.ngeom - nstat;
+        const GeomPlaceC gpc = geom_place_consts(m.geom_rec + 32 * (nstat + (c < nmov ? c : 0)));
         // ---------------- K: kinematics + RNE recursion (kin2.h): lane = link / dof, only the parent-dependent part per tree level
         qposL[c] = qpos_c; qvelL[c] = qvel_c;
         wave_sync();
@@ -173,6 +199,7 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
             for (int i = c; i < 9 * m.nlink; i += G) s.xmat[(size_t)i * N + e] = poseL[12 * (i / 9) + i % 9];
             for (int i = c; i < 6 * m.nlink; i += G) { const int l = (i % (3 * m.nlink)) / 3; s.lvel[(size_t)i * N + e] = recL[12 * l + (i < 3 * m.nlink ? 0 : 3) + i % 3]; }   // link w, then v(origin)
         }
+        PHASE(31);
         // ---------------- C: collision
         // G: lane = geom, world placement of every geom once per substep (LDS, next to the link poses)
         // 1: lane = candidate pair of its own env, bounding spheres; survivors -> workgroup candidate list (wave ballots)
@@ -181,11 +208,27 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
         {
             float *gw = qvelL + G;
             const int oGw = (int)(gw - E);
-            if (valid) for (int gi = c; gi < m.ngeom; gi += G) geom_place2(m.geom_rec + 32 * gi, poseL, gw + 16 * gi);
+            // placement of geom gi: static ones in the shared table, moving ones in this env's cache
+            auto gaddr = [&](int gi, const float *Ei) -> const float * { return gi < nstat ? lds + L.oGeomS + 16 * gi : Ei + oGw + 16 * (gi - nstat); };
+            const float *gcc = lds + L.oGeomC;
+            if (valid) {
+                for (int gm = c; gm < nmov; gm += G) {
+                    const GeomPlaceC k2 = gm < G ? gpc : geom_place_consts(m.geom_rec + 32 * (nstat + gm));
+                    m3 Rl; v3 pl;
+                    pose_load(poseL + 12 * k2.link, Rl, pl);
+                    geom_place3(k2, Rl, pl, gw + 16 * gm);
+                }
+            }
             for (int p0 = 0; p0 < m.npair_pad / 4; p0 += G) { const int p = p0 + c; if (p < m.npair_pad / 4) reinterpret_cast<int *>(pcnt)[p] = 0; }
             wave_sync();
+            PHASE(30);
             const float4 *pg4 = reinterpret_cast<const float4 *>(m.pair_geo);
+            const unsigned *sPair = reinterpret_cast<const unsigned *>(lds + L.oPair);
+            unsigned short *sCand = reinterpret_cast<unsigned short *>(poly);      // 128 entries in the box-box polygon scratch (dead during the culls)
             int ncand = 0, nitems = 0;                             // wave-uniform
+            int nit_env[EPB];                                      // items per env (wave-uniform): an env keeps at most 64, whatever its neighbours do
+#pragma unroll
+            for (int j = 0; j < EPB; j++) nit_env[j] = 0;
             // level 2 over the first min(ncand, 64) candidates of the list; the rest moves to the front
             auto box_round = [&]() {
                 const int take = ncand < 64 ? ncand : 64;
@@ -193,13 +236,24 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
                 int it = 0;
                 if (tid < take) {
                     it = sCand[tid];
-                    const float *gwi = lds + (size_t)(it >> 14) * L.envf + oGw;
-                    const float4 a = pg4[2 * (it & 0x3fff)];
-                    const int g1 = (int)a.x & 255, g2 = (int)a.y;
-                    pass = pair_cull_box(geom_cached(gwi + 16 * g1, m.geom_rec + 32 * g1, m.mesh_vert4), geom_cached(gwi + 16 * g2, m.geom_rec + 32 * g2, m.mesh_vert4), a.z, a.w);
+                    const float *Ei = lds + (size_t)(it >> 14) * L.envf;
+                    const unsigned pk = sPair[it & 0x3fff];
+                    const int g1 = pk_g1(pk), g2 = pk_g2(pk);
+                    float rb1, rb2;
+                    const Geom A = geom_cached3(gaddr(g1, Ei), gcc + 8 * g1, m.mesh_vert4, rb1), B = geom_cached3(gaddr(g2, Ei), gcc + 8 * g2, m.mesh_vert4, rb2);
+                    pass = pair_cull_box_nb(A, B, rb1, rb2);
                 }
-                const unsigned long long bal = __ballot(pass);
-                if (pass) { const int kk = nitems + __popcll(bal & ((1ull << tid) - 1ull)); if (kk < 64) sItems[kk] = (unsigned short)it; }
+                const unsigned long long lower = (1ull << tid) - 1ull;
+                const int ig = it >> 14;
+                bool accept = false;
+#pragma unroll
+                for (int j = 0; j < EPB; j++) {
+                    const unsigned long long bj = __ballot(pass && ig == j);
+                    if (pass && ig == j) accept = nit_env[j] + __popcll(bj & lower) < 64;
+                    nit_env[j] += __popcll(bj);
+                }
+                const unsigned long long bal = __ballot(accept);
+                if (accept) sItems[nitems + __popcll(bal & lower)] = (unsigned short)it;
                 nitems += __popcll(bal);
                 const int rest = ncand - take;
                 unsigned short mv = 0;
@@ -209,46 +263,66 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
                 wave_sync();
                 ncand = rest;
             };
-            for (int pb = 0; pb < m.npair; pb += 8 * G) {
-                // the records of eight chunks of G pairs are fetched together (one round trip to L2, not eight) and tested;
-                // the compaction then walks the eight result bits
-                float4 a[8];
+            // level 1: lane c of every env tests eight consecutive pairs per pass (their packed records are two LDS reads, the
+            // positions / plane normals 24 more, all issued before the first test); the survivors of all envs are appended to the
+            // workgroup's candidate list, one result bit at a time (wave ballots), and the list is box-culled whenever 64
+            // candidates are pending and once at the end - a single call site
+            {
+                const int npair8 = (m.npair_pad + 7) & ~7;
+                int pb = 0, u = 8, p0 = 0;
+                unsigned mybits = 0;
+                for (;;) {
+                    if (u == 8 && pb < m.npair) {
+                        p0 = pb + 8 * c;
+                        uint4 k0 = make_uint4(0, 0, 0, 0), k1 = k0;
+                        if (p0 < npair8) { k0 = *reinterpret_cast<const uint4 *>(sPair + p0); k1 = *reinterpret_cast<const uint4 *>(sPair + p0 + 4); }
+                        const unsigned pk[8] = {k0.x, k0.y, k0.z, k0.w, k1.x, k1.y, k1.z, k1.w};
+                        float4 a1[8], a2[8], nn[8];
 #pragma unroll
-                for (int u = 0; u < 8; u++) { const int p = pb + u * G + c; a[u] = pg4[2 * (p < m.npair ? p : 0)]; }
-                unsigned int mybits = 0;
+                        for (int q = 0; q < 8; q++) { const float *w1 = gaddr(pk_g1(pk[q]), E), *w2 = gaddr(pk_g2(pk[q]), E); a1[q] = kl4(w1); a2[q] = kl4(w2); nn[q] = kl4(w1 + 12); }
+                        mybits = 0;
 #pragma unroll
-                for (int u = 0; u < 8; u++) {
-                    const int p = pb + u * G + c, code = (int)a[u].x;
-                    if (valid && p < m.npair && pair_cull_sphere((code >> 8) ? GEOM_PLANE : GEOM_BOX, gw + 16 * (code & 255), gw + 16 * (int)a[u].y, a[u].z, a[u].w)) mybits |= 1u << u;
-                }
-                for (int u = 0; u < 8 && pb + u * G < m.npair; u++) {
-                    const int p = pb + u * G + c;
-                    const bool pass = (mybits >> u) & 1u;
-                    const unsigned long long bal = __ballot(pass);
-                    if (pass) sCand[ncand + __popcll(bal & ((1ull << tid) - 1ull))] = (unsigned short)((g << 14) | p);   // ncand < 64 here
-                    ncand += __popcll(bal);
-                    if (ncand >= 64) { wave_sync(); box_round(); }
+                        for (int q = 0; q < 8; q++) {
+                            const float rad = __uint_as_float(pk[q] & 0xffff0000u);
+                            const v3 r = mk3(a2[q].x - a1[q].x, a2[q].y - a1[q].y, a2[q].z - a1[q].z);
+                            const float dpl = dot(r, mk3(nn[q].x, nn[q].y, nn[q].z)), dsq = dot(r, r);
+                            const bool hit = pk_fn(pk[q]) <= FN_PLANE_CONVEX ? dpl <= rad : dsq <= rad * rad;
+                            mybits |= (valid && p0 + q < m.npair && hit) ? 1u << q : 0u;
+                        }
+                        u = 0; pb += 8 * G;
+                    }
+                    while (u < 8 && ncand < 64) {
+                        const bool pass = (mybits >> u) & 1u;
+                        const unsigned long long bal = __ballot(pass);
+                        if (pass) sCand[ncand + __popcll(bal & ((1ull << tid) - 1ull))] = (unsigned short)((g << 14) | (p0 + u));
+                        ncand += __popcll(bal);
+                        u++;
+                    }
+                    const bool more = u < 8 || pb < m.npair;
+                    if (ncand >= 64 || (!more && ncand > 0)) { wave_sync(); box_round(); }
+                    else if (!more) break;
                 }
             }
             wave_sync();
             PHASE(19);
-            while (ncand > 0) box_round();
-            if (nitems > 64) bad = 1;                              // more than 64 surviving pairs in one workgroup: contacts would be dropped
+#pragma unroll
+            for (int j = 0; j < EPB; j++) if (g == j && nit_env[j] > 64) bad = 1;      // more than 64 surviving pairs in ONE env: its contacts beyond them are dropped
             DBGCNT(2, nitems);
-            if (nitems > 64) nitems = 64;
             wave_sync();
-            {
+            for (int ib = 0; ib < nitems; ib += 64) {
                 // every section rebuilds the geoms it needs from the placement cache, so that nothing but the item id
                 // stays live across the register-hungry narrowphases
-                const bool act = tid < nitems;
-                const int it = act ? sItems[tid] : 0;
-                const int fn = act ? (int)pg4[2 * (it & 0x3fff) + 1].x : -1;
+                const bool act = ib + tid < nitems;
+                const int it = act ? sItems[ib + tid] : 0;
+                const int fn = act ? pk_fn(sPair[it & 0x3fff]) : -1;
                 auto item_geoms = [&](int item, Geom &A, Geom &B, ContactOut &o, unsigned char *&cntp) {
                     const int ig = item >> 14, p = item & 0x3fff;
                     float *Ei = lds + (size_t)ig * L.envf;
-                    const float4 pa = pg4[2 * p], pb = pg4[2 * p + 1];
-                    A = geom_cached(Ei + oGw + 16 * ((int)pa.x & 255), m.geom_rec + 32 * ((int)pa.x & 255), m.mesh_vert4);
-                    B = geom_cached(Ei + oGw + 16 * (int)pa.y, m.geom_rec + 32 * (int)pa.y, m.mesh_vert4);
+                    const unsigned pk = sPair[p];
+                    const float4 pb = pg4[2 * p + 1];
+                    float rb;
+                    A = geom_cached3(gaddr(pk_g1(pk), Ei), gcc + 8 * pk_g1(pk), m.mesh_vert4, rb);
+                    B = geom_cached3(gaddr(pk_g2(pk), Ei), gcc + 8 * pk_g2(pk), m.mesh_vert4, rb);
                     o.con = s.con + (size_t)(blockIdx.x * EPB + ig) * m.nslot * 8; o.slot = (int)pb.y; o.maxcnt = (int)pb.z; o.cnt = 0;
                     cntp = reinterpret_cast<unsigned char *>(Ei + L.oCnt) + p;
                 };
@@ -271,7 +345,7 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
                     for (int r0 = 0; r0 < ncv; r0 += 64 / MW) {
                         const int k = r0 + tid / MW;
                         if (k < ncv) {
-                            const int it2 = sItems[sMpr[k]];
+                            const int it2 = sItems[ib + sMpr[k]];
                             Geom H1, H2; ContactOut o2; unsigned char *cntp;
                             item_geoms(it2, H1, H2, o2, cntp);
                             float *sx = s.sepax + (size_t)(3 * (it2 & 0x3fff)) * N + (blockIdx.x * EPB + (it2 >> 14));
@@ -307,7 +381,7 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
                         const int k = r0 + tid / 8;
                         if (k < nbb) {
                             Geom G1, G2; ContactOut out; unsigned char *cntp;
-                            item_geoms(sItems[sMpr[k]], G1, G2, out, cntp);
+                            item_geoms(sItems[ib + sMpr[k]], G1, G2, out, cntp);
                             const int cnt = collide_box_box_w8(G1, G2, out.con, out.slot, out.maxcnt, poly + 24 * (tid / 8));
                             if ((tid & 7) == 0) *cntp = (unsigned char)cnt;
                         }
