@@ -1060,7 +1060,7 @@ __global__ void __launch_bounds__(64) k_narrow(DevModel m, DevState s) {
             else {
                 // temporal coherence: the separating direction MPR proved last time is tried first; if it still
                 // separates (two support calls), MPR would again report "no intersection" - identical result
-                float *sx = s.sepax + (size_t)(3 * p) * N + e;
+                float *sx = s.sepax + (size_t)(4 * p) * N + e;          // rows 4 p .. 4 p + 2: direction; row 4 p + 3: margin cache of the persistent kernel
                 const v3 d = mk3(sx[0], sx[N], sx[2 * (size_t)N]);
                 bool still = false;
                 if (d.x != 0.f || d.y != 0.f || d.z != 0.f) still = dot(support(G1, d) - support(G2, -d), d) < -1e-7f;

@@ -284,6 +284,7 @@ __global__ void k_reset(DevModel m, DevState s, const uint8_t *mask, const float
     for (int i = 0; i < m.nu; i++) s.ctrl[(size_t)i * N + e] = 0;
     for (int k = 0; k < 3; k++) s.mocap[(size_t)k * N + e] = mocap ? mocap[(size_t)e * 3 + k] : 0.f;
     s.time[e] = 0; s.bad[e] = 0; s.nsteps[e] = 0;
+    for (int p = 0; p < m.npair; p++) s.sepax[(size_t)(4 * p + 3) * N + e] = 0.f;     // the geoms jumped: no separation margin is left
 }
 __global__ void k_body_xpos(DevModel m, DevState s, int body, float *out) {
     int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -489,13 +490,14 @@ extern "C" int hsr_batch_create(const hsr_model *m, int n_envs, int device_id, h
     DevState &s = b->ds;
     const size_t N = (size_t)n_envs;
     s.N = n_envs;
+    s.npair_sep = std::max(d.npair, 1);
 #define DA(field, rows) if ((rc = dalloc(b, &s.field, (size_t)(rows) * N))) return rc;
     DA(qpos, d.nq) DA(qvel, d.nv) DA(ctrl, d.nu) DA(mocap, 3) DA(warm, d.nv) DA(time, 1)
     DA(done, 1) DA(bad, 1) DA(nsteps, 1)
     DA(xpos, 3 * d.nlink) DA(xmat, 9 * d.nlink) DA(lvel, 6 * d.nlink) DA(dof_ang, 3 * d.nv) DA(dof_lin, 3 * d.nv) DA(dof_anchor, 3 * d.nv) DA(link_dyn, 15 * d.nlink)
     s.kstride = (9 * d.nv + 15 * d.nlink + 15) & ~15;
     DA(kin_aos, s.kstride)
-    DA(con, 8 * d.nslot) DA(ncon_pair, d.npair_pad) DA(sepax, 3 * std::max(d.npair, 1)) DA(pair_list, std::max(d.npair, 1))
+    DA(con, 8 * d.nslot) DA(ncon_pair, d.npair_pad) DA(sepax, 4 * std::max(d.npair, 1)) DA(pair_list, std::max(d.npair, 1))
     if ((rc = dalloc(b, &s.pair_count, (size_t)d.npair_pad))) return rc;
     DA(M, d.nM) DA(qacc, d.nv) DA(qacc_smooth, d.nv) DA(qfrc_smooth, d.nv) DA(qfrc_constraint, d.nv)
     DA(ncon, 1) DA(nefc, 1) DA(niter, 1)
@@ -623,7 +625,19 @@ extern "C" void *hsr_batch_stream(const hsr_batch *b) { return (void *)b->stream
 extern "C" int hsr_batch_sync(hsr_batch *b) { HIPCHK(hipSetDevice(b->device)); HIPCHK(hipStreamSynchronize(b->stream)); return HSR_OK; }
 extern "C" int hsr_batch_set_profiling(hsr_batch *b, int on) { b->profiling = on != 0; return HSR_OK; }
 extern "C" int hsr_batch_set_graph(hsr_batch *b, int on) { b->use_graph = on != 0; return HSR_OK; }
-extern "C" int hsr_batch_set_persistent(hsr_batch *b, int on) { b->persist = on != 0 && b->persist_ok; return b->persist ? 1 : 0; }
+__global__ void k_clear_margins(DevState s) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < (size_t)s.npair_sep * s.N) s.sepax[(4 * (i / s.N) + 3) * s.N + i % s.N] = 0.f;
+}
+static void clear_margins(hsr_batch *b) {
+    hipLaunchKernelGGL(k_clear_margins, grid1((size_t)b->ds.npair_sep * b->N), dim3(256), 0, b->stream, b->ds);
+}
+extern "C" int hsr_batch_set_persistent(hsr_batch *b, int on) {
+    const bool want = on != 0 && b->persist_ok;
+    if (want && !b->persist) { hipSetDevice(b->device); clear_margins(b); }      // the per-substep chain does not maintain the margins
+    b->persist = want;
+    return b->persist ? 1 : 0;
+}
 extern "C" int hsr_batch_is_persistent(const hsr_batch *b) { return b->persist ? 1 : 0; }
 
 // one substep = 3 launches on the batch stream
@@ -716,6 +730,7 @@ extern "C" int hsr_batch_get_state(hsr_batch *b, float *time, float *qpos, float
 }
 extern "C" int hsr_batch_set_state(hsr_batch *b, const float *time, const float *qpos, const float *qvel) {
     HIPCHK(hipSetDevice(b->device));
+    clear_margins(b);                     // positions jump: the separation margins of the convex pairs are void
     int rc;
     if (time && (rc = to_device_soa(b, b->ds.time, time, 1))) return rc;
     if (qpos && (rc = to_device_soa(b, b->ds.qpos, qpos, b->dm.nq))) return rc;

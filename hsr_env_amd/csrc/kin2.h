@@ -213,7 +213,9 @@ __device__ __forceinline__ GeomPlaceC geom_place_consts(const float *rec) {
     k.link = (int)q0.x; k.type = (int)q0.y;
     return k;
 }
-__device__ __forceinline__ void geom_place3(const GeomPlaceC &k, const m3 &R, v3 pl, float *out) {
+// step_move: upper bound of how far any point of the geom moved since the previous substep (0 for a static geom); it feeds the
+// separation-margin cache of the convex pairs (persist.h)
+__device__ __forceinline__ void geom_place3(const GeomPlaceC &k, const m3 &R, v3 pl, float *out, float step_move = 0.f) {
     m3 lm;
     lm.a[0] = k.q2.x; lm.a[1] = k.q2.y; lm.a[2] = k.q2.z; lm.a[3] = k.q2.w; lm.a[4] = k.q3.x; lm.a[5] = k.q3.y; lm.a[6] = k.q3.z; lm.a[7] = k.q3.w; lm.a[8] = k.q4.x;
     const v3 pos = pl + mulmv(R, mk3(k.q1.x, k.q1.y, k.q1.z));
@@ -221,7 +223,7 @@ __device__ __forceinline__ void geom_place3(const GeomPlaceC &k, const m3 &R, v3
     v3 bc = pos + mulmv(mat, mk3(k.q5.x, k.q5.y, k.q5.z));
     if (k.type == GEOM_PLANE) bc = col(mat, 2);
     ks4(out, make_float4(pos.x, pos.y, pos.z, mat.a[0])); ks4(out + 4, make_float4(mat.a[1], mat.a[2], mat.a[3], mat.a[4]));
-    ks4(out + 8, make_float4(mat.a[5], mat.a[6], mat.a[7], mat.a[8])); ks4(out + 12, make_float4(bc.x, bc.y, bc.z, 0.f));
+    ks4(out + 8, make_float4(mat.a[5], mat.a[6], mat.a[7], mat.a[8])); ks4(out + 12, make_float4(bc.x, bc.y, bc.z, step_move));
 }
 __device__ __forceinline__ void geom_consts_store(const float *rec, float *out) {
     const float4 *r4 = reinterpret_cast<const float4 *>(rec);

@@ -54,7 +54,8 @@ struct DevState {
     float *con;
     int *ncon_pair;
     int *pair_count, *pair_list;   // per-pair work lists of the narrowphase: count[npair_pad], list[npair][N] env ids
-    float *sepax;             // [3 npair][N] cached separating direction per (pair, env) for the MPR pairs (0 = none)
+    float *sepax;             // [4 npair][N] per (pair, env) of the MPR pairs: cached separating direction (0 = none), then the separation left along it
+    int npair_sep;            // rows of sepax / 4
     // dynamics / solver outputs kept for introspection
     float *M, *qacc, *qacc_smooth, *qfrc_smooth, *qfrc_constraint;
     int *ncon, *nefc, *niter;

@@ -216,7 +216,12 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
                     const GeomPlaceC k2 = gm < G ? gpc : geom_place_consts(m.geom_rec + 32 * (nstat + gm));
                     m3 Rl; v3 pl;
                     pose_load(poseL + 12 * k2.link, Rl, pl);
-                    geom_place3(k2, Rl, pl, gw + 16 * gm);
+                    // the geom moved since the previous substep by at most h (|v(geom origin)| + |w| rbound), v and w being this
+                    // substep's link velocities (qpos advanced with exactly this qvel); 25 % cover the curvature of the path
+                    const float4 lv0 = kl4(recL + 12 * k2.link);
+                    const v3 lw = mk3(lv0.x, lv0.y, lv0.z), lvo = mk3(lv0.w, recL[12 * k2.link + 4], recL[12 * k2.link + 5]);
+                    const v3 vg = lvo + cross(lw, mulmv(Rl, mk3(k2.q1.x, k2.q1.y, k2.q1.z)));
+                    geom_place3(k2, Rl, pl, gw + 16 * gm, 1.25f * m.timestep * (norm(vg) + norm(lw) * k2.q1.w) + 1e-7f);
                 }
             }
             for (int p0 = 0; p0 < m.npair_pad / 4; p0 += G) { const int p = p0 + c; if (p < m.npair_pad / 4) reinterpret_cast<int *>(pcnt)[p] = 0; }
@@ -348,10 +353,25 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
                             const int it2 = sItems[ib + sMpr[k]];
                             Geom H1, H2; ContactOut o2; unsigned char *cntp;
                             item_geoms(it2, H1, H2, o2, cntp);
-                            float *sx = s.sepax + (size_t)(3 * (it2 & 0x3fff)) * N + (blockIdx.x * EPB + (it2 >> 14));
+                            // temporal coherence: the direction d that separated the pair last time, and how much of that
+                            // separation is left after the geoms' moves since (upper bounds, geom cache slot 15): while it is
+                            // positive the pair is still separated along d and nothing is scanned; otherwise both hulls are scanned
+                            // along d and the margin is refreshed; MPR runs only when d no longer separates
+                            float *sx = s.sepax + (size_t)(4 * (it2 & 0x3fff)) * N + (blockIdx.x * EPB + (it2 >> 14));
                             const v3 d = mk3(sx[0], sx[N], sx[2 * (size_t)N]);
-                            bool still = false;
-                            if (d.x != 0.f || d.y != 0.f || d.z != 0.f) still = dot(support<MW>(H1, d) - support<MW>(H2, -d), d) < -1e-7f;
+                            float mg = sx[3 * (size_t)N];
+                            {
+                                const unsigned pk2 = sPair[it2 & 0x3fff];
+                                const float *Ei2 = lds + (size_t)(it2 >> 14) * L.envf;
+                                mg -= gaddr(pk_g1(pk2), Ei2)[15] + gaddr(pk_g2(pk2), Ei2)[15];
+                            }
+                            const bool have = d.x != 0.f || d.y != 0.f || d.z != 0.f;
+                            bool still = have && mg > 0.f;
+                            if (have && !still) {
+                                const float gap = -dot(support<MW>(H1, d) - support<MW>(H2, -d), d);
+                                still = gap > 1e-7f;
+                                mg = still ? 0.98f * gap : 0.f;
+                            }
                             if (!still) {
                                 float depth; v3 dir, pos, sep;
                                 int nsup = 0;
@@ -359,11 +379,13 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
 #ifdef HSR_PHASE_TIMING
                                 if ((tid & (MW - 1)) == 0) { atomicAdd(&sDbg[0], nsup); atomicAdd(&sDbg[1], 1); atomicMax(&sDbg[2], nsup); }
 #endif
+                                mg = 0.f;
                                 if ((tid & (MW - 1)) == 0) {
                                     if (hit) { o2.add(pos, dir, -depth); sep = mk3(0, 0, 0); }
                                     sx[0] = sep.x; sx[N] = sep.y; sx[2 * (size_t)N] = sep.z;
                                 }
                             }
+                            if ((tid & (MW - 1)) == 0) sx[3 * (size_t)N] = mg;
                             if ((tid & (MW - 1)) == 0) *cntp = (unsigned char)o2.cnt;
                         }
                     }

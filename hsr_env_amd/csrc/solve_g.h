@@ -15,6 +15,13 @@
 #include "solve.h"
 #include <type_traits>
 
+// relative stop of the exact line search: |phi'(alpha)| < HSR_LS_REL |phi'(0)|
+#ifndef HSR_LAST_DEC
+#define HSR_LAST_DEC 1e-6f      // 100 x the solver tolerance of 1e-8 (solve_body.inc, Newton loop)
+#endif
+#ifndef HSR_LS_REL
+#define HSR_LS_REL 1e-3f
+#endif
 #ifdef HSR_PHASE_TIMING
 // diagnostic build only: stamp = one asm statement (s_memtime + its wait) fenced by sched_barriers, sums kept in
 // registers and flushed once at the end (cdna_hip_programming.md section 7, in-kernel stamps)
@@ -111,6 +118,15 @@ template <int G> __device__ __forceinline__ int gmax(int v) {    // maximum over
     { const int t = dpp_i<0x122, true>(v); v = t > v ? t : v; } { const int t = dpp_i<0x121, true>(v); v = t > v ? t : v; }
     if constexpr (G == 16) return v;
     else { const auto sw = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false); const int a = (int)sw[0], b = (int)sw[1]; return a > b ? a : b; }
+}
+// OR / maximum of a group-uniform value over the env groups of the wave, as a scalar (v_readlane ignores EXEC: call it from
+// wave-uniform control flow only, with the value defined in every lane)
+template <int G> __device__ __forceinline__ int wave_or_groups(int v) {
+    if constexpr (G == 16) return rl_(v, 0) | rl_(v, 16) | rl_(v, 32) | rl_(v, 48); else return rl_(v, 0) | rl_(v, 32);
+}
+template <int G> __device__ __forceinline__ int wave_max_groups(int v) {
+    if constexpr (G == 16) { const int a = rl_(v, 0), b = rl_(v, 16), c = rl_(v, 32), d = rl_(v, 48); const int x = a > b ? a : b, y = c > d ? c : d; return x > y ? x : y; }
+    else { const int a = rl_(v, 0), b = rl_(v, 32); return a > b ? a : b; }
 }
 template <int G> __device__ __forceinline__ int glast(int v) {   // value of the last lane of the group
     if constexpr (G == 16) return dpp_i<0x15F, false>(v); else return pick32_<31, 63>(v);
