@@ -7,7 +7,10 @@ reference's driver loop (hsr/control.py:73-75) and, for N > 1, one RCCL all-gath
 Workload (config.workload): BASELINE config 3 - all 7 DOFs + 1 block, 8192 envs per GPU (weak scaling),
 synthetic inputs of SURVEY.md section 8d resident in HBM before the timed region.
 
-    python bench.py [--gpus N --steps K --warmup W]            (N > 1: launched by torch.distributed.run)
+    python bench.py [--gpus N --steps K --warmup W]
+N > 1 works both ways: under `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` (RANK / WORLD_SIZE in
+the environment) and as the plain command above, which then starts the N ranks itself (one child process per GPU; the parent
+never touches the GPU) and relays rank 0's JSON line.
 """
 from __future__ import annotations
 
@@ -67,16 +70,17 @@ def host_cores():
 
 def cpu_baseline(m, q0, goal, ctrl, cores):
     """Oracle (fp64 C restatement, OpenMP over envs) on the host cores, bounded sample of the same workload:
-    a calibration pass on 8 envs per thread sizes the sample (first n envs, r env-steps) to about 12 s."""
+    a calibration pass on 8 envs per thread sizes the sample (first n envs, r env-steps) to about 12 s; then the same
+    code on ONE thread for about 5 s (single-core and all-core)."""
     from oracle import oracle as orc
     bid = m.body_id(m.block_body()) if m.block_body() else -1
 
-    def run(n, reps):
+    def run(n, reps, threads=cores):
         qpos = q0[:n].astype(np.float64).copy(); qvel = np.zeros((n, m.nv)); warm = np.zeros((n, m.nv))
         mocap = goal[:n].astype(np.float64).copy()
         t0 = time.perf_counter()
         for k in range(reps):
-            orc.batch_env_step(m, qpos, qvel, warm, ctrl[k % len(ctrl)][:n].astype(np.float64).copy(), mocap, STEPS_PER_ACTION, bid, GEOFENCE, cores)
+            orc.batch_env_step(m, qpos, qvel, warm, ctrl[k % len(ctrl)][:n].astype(np.float64).copy(), mocap, STEPS_PER_ACTION, bid, GEOFENCE, threads)
         return time.perf_counter() - t0
 
     N = q0.shape[0]
@@ -86,10 +90,34 @@ def cpu_baseline(m, q0, goal, ctrl, cores):
     n = int(min(N, max(n_cal, budget / max(per_env_step, 1e-9))))
     reps = int(max(1, min(8, budget / max(per_env_step * n, 1e-9))))
     dt = run(n, reps)
+    n1 = int(max(1, min(n, 5.0 / max(per_env_step * cores, 1e-9))))     # about 5 s on one thread
+    dt1 = run(n1, 1, threads=1)
     return dict(value=n * reps / dt, unit="env-steps/s", cores=cores, kind="port",
+                single_core={"value": n1 / dt1, "unit": "env-steps/s", "cores": 1, "sample": f"first {n1} envs x 1 env-step ({dt1:.1f} s)"},
                 sample=f"first {n} envs x {reps} env-steps x {STEPS_PER_ACTION} substeps of the same workload ({dt:.1f} s), "
                        f"oracle/hsr_oracle.c fp64 with OpenMP over envs ({cores} threads); stand-in for CPU mujoco-py, "
                        "which is not installable here")
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script (env:// rendezvous on 127.0.0.1), relay rank
+    0's output, fail if any rank fails.  Runs before torch / HIP are touched - the parent process never initialises the GPU."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out)
+    sys.stdout.flush()
+    return next((c for c in codes if c), 0)
 
 
 def main():
@@ -106,6 +134,8 @@ def main():
                     help="control-flow rehearsal of the N>1 path on a box with one GPU: every rank uses cuda:0 and the all-gather "
                          "goes through gloo on host copies (RCCL refuses two ranks on one device); the number it prints is not a result")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args))
 
     import torch
     from hsr_env_amd.compiler import load_config
@@ -234,22 +264,45 @@ def main():
     value = world * n * K / dt
     mean_substeps = float(substeps_done.item()) / (n * K)
     bad, any_bad = sim.bad_state()
+    cap_con, cap_row, cap_item, cap_total = sim.cap_counts()
+    nblocks = len(m.free_joint_qadrs())
+    dofs = {2: "slide_x/slide_y DOFs only", 7: "all 7 DOFs"}.get(m.nu, f"{m.nu} actuated DOFs")
+    baseline_cfg = {"cfg1": "BASELINE config 1 shape", "cfg2": "BASELINE config 2", "cfg3": "BASELINE config 3",
+                    "cfg4": "BASELINE configs 4/5 per-GPU shard"}.get(args.config, "SURVEY 8f scene")
+    # the roofline that binds: FP32 VALU issue.  Wave-instructions per wave per substep come from the committed
+    # PMC pass of this kernel (profiles/pmc_summary.json, SQ_INSTS_VALU); peak = 1024 SIMD-32 x 2.4 GHz / 2 clocks per wave64 op
+    valu = None
+    try:
+        sq = json.loads(pmc.read_text()).get("_sq_per_wave_per_substep", {}) if pmc.exists() else {}
+        if persistent and args.config == "cfg3" and "SQ_INSTS_VALU" in sq:
+            waves = (n * (16 if m.nv <= 16 else 32) + 63) // 64
+            ips = sq["SQ_INSTS_VALU"] * waves * mean_substeps / (avg_us * 1e-6)
+            peak_ips = 1024 * 2.4e9 / 2
+            valu = {"wave_instr_per_s": ips, "peak": peak_ips, "frac": ips / peak_ips, "flop_per_s_estimate": ips * 64 * 1.3,
+                    "source": "profiles/pmc_summary.json _sq_per_wave_per_substep.SQ_INSTS_VALU x waves x substeps / measured launch time; "
+                              "flop estimate = lanes x ~1.3 flop per VALU instruction (fma share), most lanes of a 16-lane group idle in the serial phases"}
+    except Exception:
+        valu = None
 
     out = {
-        "metric": "env-steps/sec (whole node), HSR+1-block, steps_per_action=300, 8192 envs",
+        "metric": f"env-steps/sec (whole node), HSR+{nblocks}-block, steps_per_action={STEPS_PER_ACTION}, {n} envs",
         "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
         "ms_per_step": 1e3 * dt / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"BASELINE config 3: {args.config} all 7 DOFs + 1 block, {n} envs per GPU x {world} GPU(s), "
+        "config": {"workload": f"{baseline_cfg}: {args.config}, {dofs} + {nblocks} block(s), {n} envs per GPU x {world} GPU(s), "
                                f"steps_per_action={STEPS_PER_ACTION}, geofence={GEOFENCE}, ctrl~U(ctrlrange) per env-step, done envs reset",
                    "envs_per_gpu": n, "global_envs": world * n, "substeps_per_env_step": STEPS_PER_ACTION,
                    "mean_substeps_executed": mean_substeps, "done_fraction": float(dones.item()) / (n * K),
-                   "parallelism": f"env-shard x{world}" + (" + all-gather(obs,reward,done)" if world > 1 else ""),
+                   "parallelism": f"env-shard x{world}" + (f" + all-gather(obs,reward,done) over {'gloo (rehearsal)' if args.rehearse_on_one_gpu else 'RCCL'}, {dist.get_world_size()} ranks" if world > 1 else ""),
+                   "cap_hits": {"contacts_beyond_nconmax": cap_con / max(cap_total, 1), "rows_beyond_njmax": cap_row / max(cap_total, 1),
+                                "items_beyond_64_per_env": cap_item / max(cap_total, 1), "env_substeps": cap_total,
+                                "nconmax_njmax": [int(m.arrays["sizes"][10]), int(m.arrays["sizes"][11])], "note": "fraction of (env, substep) pairs; MuJoCo's own caps are 100 / 500 (world.xml:44)"},
                    "substeps_per_s": value * mean_substeps, "persistent_kernel": persistent, "hipgraph": (not args.no_graph) and not persistent,
                    "bad_envs": int(bad.sum())},
         "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                      "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_us": avg_us,
+                     "valu": valu,
                      "kernel_ms_per_env_step": {nm: ms for nm, ms in zip(names, k_ms) if nm != "-"},
                      "launches_per_env_step": {nm: k for nm, k in zip(names, k_n) if nm != "-"},
                      "note": "state stays L2/MALL-resident; the path is FP32-VALU/latency bound, not HBM bound (SURVEY.md 8d)"},

@@ -43,6 +43,7 @@ GEOM_TYPES = {"plane": GEOM_PLANE, "sphere": GEOM_SPHERE, "cylinder": GEOM_CYLIN
 DOF_SLIDE, DOF_HINGE, DOF_FREE_LIN, DOF_FREE_ANG = 0, 1, 2, 3
 # narrowphase function per candidate pair
 FN_PLANE_BOX, FN_PLANE_CONVEX, FN_BOX_BOX, FN_CONVEX = 0, 1, 2, 3
+UNLIMITED = 1e30     # range of an actuator without ctrllimited / forcelimited (finite in fp32)
 FN_MAXCON = {FN_PLANE_BOX: 4, FN_PLANE_CONVEX: 1, FN_BOX_BOX: 8, FN_CONVEX: 1}
 
 DEFAULT_REF_ROOT = Path("/root/reference/hsr")
@@ -789,8 +790,14 @@ def compile_model(dofs: Sequence[str] = ("slide_x", "slide_y"), n_blocks: int = 
     act_dof = np.array([joint_dofadr[joint_names.index(a.get("joint"))] for a in acts], dtype=np.int32)
     act_gear = np.array([float(a.get("gear", 1)) for a in acts])
     act_kp = np.array([float(a.get("kp", 1)) for a in acts])
-    act_ctrlrange = np.array([_vec(a.get("ctrlrange"), 2, [0, 0]) for a in acts]).reshape(-1, 2)
-    act_forcerange = np.array([_vec(a.get("forcerange"), 2, [0, 0]) for a in acts]).reshape(-1, 2)
+    # MuJoCo clamps ctrl / actuator force only when ctrllimited / forcelimited is set (world.xml:104-124 sets both on all seven
+    # actuators); an unlimited actuator gets an effectively infinite range so that the kernels' unconditional clamp is a no-op
+    def _range(a, key, flag):
+        if a.get(flag, "false") != "true" or a.get(key) is None:
+            return [-UNLIMITED, UNLIMITED]
+        return _vec(a.get(key), 2, [0, 0])
+    act_ctrlrange = np.array([_range(a, "ctrlrange", "ctrllimited") for a in acts], dtype=np.float64).reshape(-1, 2)
+    act_forcerange = np.array([_range(a, "forcerange", "forcelimited") for a in acts], dtype=np.float64).reshape(-1, 2)
 
     # bit k of link_dofmask[l] is set when dof k lies on the path from link l to the root
     link_dofmask = np.zeros(nlink, dtype=np.int32)
@@ -924,6 +931,15 @@ CONFIGS = {
     # hsr/__init__.py:10-19 demo; many more box geoms -> 274 candidate pairs
     "cupboard": dict(dofs=ALL_DOFS, n_blocks=0, xml_file="models/cupboard-world.xml"),
 }
+# further committed blobs, used by the parity tests only (the GPU box has no reference tree to compile from):
+#   cfg3_setxml  SURVEY 8f row 2: cfg3 through `--set-xml` (pan friction halved, arm-lift actuator without ctrl limit)
+#   nq18         a model whose qpos (18) does not fit the 16 lanes its 16 dofs select: must fall back to the per-substep chain
+TEST_CONFIGS = {
+    "cfg3_setxml": dict(dofs=ALL_DOFS, n_blocks=1,
+                        set_xml=[("worldbody/body[@name='pan']/geom/friction", "0.5 0.005 0.0001"),
+                                 ("actuator/position[@name='arm_lift_motor']/ctrllimited", "false")]),
+    "nq18": dict(dofs=["slide_x", "slide_y", "arm_lift_joint", "arm_flex_joint"], n_blocks=2),
+}
 MODEL_DIR = Path(__file__).parent / "models"
 
 
@@ -932,9 +948,62 @@ def load_config(name: str) -> Model:
     return Model.load(MODEL_DIR / f"{name}.hsrm")
 
 
+def emit_mjcf(outdir, name: str, dofs: Sequence[str] = ("slide_x", "slide_y"), n_blocks: int = 0,
+              block_pos: Optional[np.ndarray] = None, xml_file: str = "models/world.xml",
+              ref_root: Path = DEFAULT_REF_ROOT, set_xml: Sequence = ()) -> Path:
+    """Write the MJCF that the reference's launcher would hand to mujoco-py for this configuration - the mutations of
+    hsr/util.py:93-159 (block injection, --set-xml, actuator / joint filter, include and meshdir paths) applied to the
+    main file and to every included file - as <outdir>/<name>.xml (+ <name>__<include>).  Anyone with a MuJoCo install
+    can load it to generate external golden vectors (tests/test_mujoco_crosscheck.py)."""
+    ref_root, outdir = Path(ref_root), Path(outdir)
+    outdir.mkdir(parents=True, exist_ok=True)
+    xml_path = ref_root / xml_file
+    if block_pos is None:
+        block_pos = np.array([[0.0, 0.12 * (i - (n_blocks - 1) / 2.0), 0.422] for i in range(n_blocks)]).reshape(n_blocks, 3)
+    set_xml = [(str(p), str(v)) for p, v in set_xml]
+    includes = [e.get("file") for e in ET.parse(xml_path).findall("*/include")]
+    out_main = outdir / f"{name}.xml"
+    for rel in [None] + includes:
+        src = xml_path if rel is None else xml_path.parent / rel
+        tree = ET.parse(src)
+        root = tree.getroot()
+        worldbody = root.find("./worldbody")
+        if worldbody is not None:
+            for i in range(n_blocks):
+                body = ET.SubElement(worldbody, "body", attrib=dict(name=f"block{i}", pos=" ".join(repr(float(x)) for x in block_pos[i])))
+                ET.SubElement(body, "geom", attrib=dict(name=f"block{i}", type="box", mass="1", size=".05 .025 .017", condim="6",
+                                                        solimp="0.99 0.99 0.01", solref="0.01 1"))
+                ET.SubElement(body, "freejoint", attrib=dict(name=f"block{i}joint"))
+        _apply_setters(root, set_xml)
+        for acts in root.iter("actuator"):
+            for a in list(acts):
+                if a.get("joint") not in dofs:
+                    acts.remove(a)
+        for body in root.iter("body"):
+            for j in body.findall("joint"):
+                if j.get("name") not in dofs:
+                    body.remove(j)
+        for inc in root.findall("*/include"):
+            inc.set("file", f"{name}__{Path(inc.get('file')).name}")
+        for comp in root.findall("compiler"):
+            comp.set("meshdir", str((xml_path.parent / comp.get("meshdir", ".")).resolve()))
+        tree.write(out_main if rel is None else outdir / f"{name}__{Path(rel).name}")
+    return out_main
+
+
 def main():
+    import argparse
+    ap = argparse.ArgumentParser(description="compile the committed model blobs / emit the mutated MJCF of each configuration")
+    ap.add_argument("--emit-mjcf", metavar="DIR", default=None,
+                    help="write <DIR>/<config>.xml (what hsr/util.py:mutate_xml yields) for every configuration instead of compiling")
+    args = ap.parse_args()
+    every = dict(CONFIGS, **TEST_CONFIGS)
+    if args.emit_mjcf:
+        for name, kw in every.items():
+            print(emit_mjcf(args.emit_mjcf, name, **kw))
+        return
     MODEL_DIR.mkdir(exist_ok=True)
-    for name, kw in CONFIGS.items():
+    for name, kw in every.items():
         m = compile_model(**kw)
         m.save(MODEL_DIR / f"{name}.hsrm")
         print(name, "nq", m.nq, "nv", m.nv, "nu", m.nu, "nlink", m.nlink, "nbody", m.nbody,

@@ -10,8 +10,7 @@
 // velocity part).  All arrays are Views so that the same code serves the one-lane-per-env kernel (LDS tile per lane)
 // and the persistent per-env-group kernel (LDS record of the group).  Outputs: link poses, world dof axes/anchors,
 // per-link com(3) Iworld(6) F(3) N(3) in ld; lw/lvo/lal/lao are scratch (12 floats per link).
-// model-constant providers for the per-link kinematics: straight from the device tables, or from registers that one
-// lane preloaded for "its" link (persistent kernel: no dependent global loads inside the tree-level rounds)
+// model-constant provider of the per-link kinematics (the persistent kernel has its own staged form in kin2.h)
 struct KinGlobal {
     const DevModel &m;
     __device__ __forceinline__ int link_dofadr(int l) const { return m.link_dofadr[l]; }
@@ -32,79 +31,6 @@ struct KinGlobal {
     __device__ __forceinline__ v3 dof_pos(int k) const { return ld3(m.dof_pos, k); }
 };
 __device__ __forceinline__ v3 sel3(bool c, v3 a, v3 b) { return mk3(c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z); }
-struct KinLane {          // constants of ONE link (the lane's) and of its first three scalar dofs
-    int dofadr, dofnum, free_, qposadr, parent;
-    v3 lpos, com;
-    m3 lmat;
-    float mass, inertia[6];
-    int dqadr0, dqadr1, dqadr2, dtype0, dtype1, dtype2;       // named members, not arrays: a dynamically indexed array would live in scratch
-    v3 daxis0, daxis1, daxis2, dpos0, dpos1, dpos2;
-    __device__ __forceinline__ void load(const DevModel &m, int l) {
-        dofadr = m.link_dofadr[l]; dofnum = m.link_dofnum[l]; free_ = m.link_free[l]; qposadr = m.link_qposadr[l]; parent = m.link_parent[l];
-        lpos = ld3(m.link_pos, l); lmat = ldm(m.link_mat, l); com = ld3(m.link_com, l); mass = m.link_mass[l];
-#pragma unroll
-        for (int i = 0; i < 6; i++) inertia[i] = m.link_inertia[6 * l + i];
-        const int k0 = dofadr, k1 = dofadr + (1 < dofnum ? 1 : 0), k2 = dofadr + (2 < dofnum ? 2 : 0);
-        dqadr0 = m.dof_qposadr[k0]; dtype0 = m.dof_type[k0]; daxis0 = ld3(m.dof_axis, k0); dpos0 = ld3(m.dof_pos, k0);
-        dqadr1 = m.dof_qposadr[k1]; dtype1 = m.dof_type[k1]; daxis1 = ld3(m.dof_axis, k1); dpos1 = ld3(m.dof_pos, k1);
-        dqadr2 = m.dof_qposadr[k2]; dtype2 = m.dof_type[k2]; daxis2 = ld3(m.dof_axis, k2); dpos2 = ld3(m.dof_pos, k2);
-    }
-    __device__ __forceinline__ int link_dofadr(int) const { return dofadr; }
-    __device__ __forceinline__ int link_dofnum(int) const { return dofnum; }
-    __device__ __forceinline__ int link_free(int) const { return free_; }
-    __device__ __forceinline__ int link_qposadr(int) const { return qposadr; }
-    __device__ __forceinline__ int link_parent(int) const { return parent; }
-    __device__ __forceinline__ v3 link_pos(int) const { return lpos; }
-    __device__ __forceinline__ m3 link_mat(int) const { return lmat; }
-    __device__ __forceinline__ v3 link_com(int) const { return com; }
-    __device__ __forceinline__ float link_mass(int) const { return mass; }
-    __device__ __forceinline__ void link_inertia(int, float *o) const {
-#pragma unroll
-        for (int i = 0; i < 6; i++) o[i] = inertia[i]; }
-    __device__ __forceinline__ int dof_qposadr(int k) const { const int j = k - dofadr; return j == 0 ? dqadr0 : (j == 1 ? dqadr1 : dqadr2); }
-    __device__ __forceinline__ int dof_type(int k) const { const int j = k - dofadr; return j == 0 ? dtype0 : (j == 1 ? dtype1 : dtype2); }
-    __device__ __forceinline__ v3 dof_axis(int k) const { const int j = k - dofadr; return sel3(j == 0, daxis0, sel3(j == 1, daxis1, daxis2)); }
-    __device__ __forceinline__ v3 dof_pos(int k) const { const int j = k - dofadr; return sel3(j == 0, dpos0, sel3(j == 1, dpos1, dpos2)); }
-};
-
-// the same constants as KinLane, read on demand from a 52-float LDS record of the link (built once per launch with
-// KinLane::store): nothing stays in registers between tree levels
-struct KinLds {
-    const float *p;
-    __device__ __forceinline__ int link_dofadr(int) const { return (int)p[0]; }
-    __device__ __forceinline__ int link_dofnum(int) const { return (int)p[1]; }
-    __device__ __forceinline__ int link_free(int) const { return (int)p[2]; }
-    __device__ __forceinline__ int link_qposadr(int) const { return (int)p[3]; }
-    __device__ __forceinline__ int link_parent(int) const { return (int)p[4]; }
-    __device__ __forceinline__ v3 link_pos(int) const { return mk3(p[5], p[6], p[7]); }
-    __device__ __forceinline__ m3 link_mat(int) const { m3 r;
-#pragma unroll
-        for (int i = 0; i < 9; i++) r.a[i] = p[8 + i];
-        return r; }
-    __device__ __forceinline__ v3 link_com(int) const { return mk3(p[17], p[18], p[19]); }
-    __device__ __forceinline__ float link_mass(int) const { return p[20]; }
-    __device__ __forceinline__ void link_inertia(int, float *o) const {
-#pragma unroll
-        for (int i = 0; i < 6; i++) o[i] = p[21 + i]; }
-    __device__ __forceinline__ int dof_qposadr(int k) const { return (int)p[27 + k - (int)p[0]]; }
-    __device__ __forceinline__ int dof_type(int k) const { return (int)p[30 + k - (int)p[0]]; }
-    __device__ __forceinline__ v3 dof_axis(int k) const { const float *q = p + 33 + 3 * (k - (int)p[0]); return mk3(q[0], q[1], q[2]); }
-    __device__ __forceinline__ v3 dof_pos(int k) const { const float *q = p + 42 + 3 * (k - (int)p[0]); return mk3(q[0], q[1], q[2]); }
-};
-enum { KINLDS_FLOATS = 52 };
-__device__ __forceinline__ void kinlds_store(const KinLane &K, float *o) {
-    o[0] = (float)K.dofadr; o[1] = (float)K.dofnum; o[2] = (float)K.free_; o[3] = (float)K.qposadr; o[4] = (float)K.parent;
-    o[5] = K.lpos.x; o[6] = K.lpos.y; o[7] = K.lpos.z;
-#pragma unroll
-    for (int i = 0; i < 9; i++) o[8 + i] = K.lmat.a[i];
-    o[17] = K.com.x; o[18] = K.com.y; o[19] = K.com.z; o[20] = K.mass;
-#pragma unroll
-    for (int i = 0; i < 6; i++) o[21 + i] = K.inertia[i];
-    o[27] = (float)K.dqadr0; o[28] = (float)K.dqadr1; o[29] = (float)K.dqadr2; o[30] = (float)K.dtype0; o[31] = (float)K.dtype1; o[32] = (float)K.dtype2;
-    o[33] = K.daxis0.x; o[34] = K.daxis0.y; o[35] = K.daxis0.z; o[36] = K.daxis1.x; o[37] = K.daxis1.y; o[38] = K.daxis1.z; o[39] = K.daxis2.x; o[40] = K.daxis2.y; o[41] = K.daxis2.z;
-    o[42] = K.dpos0.x; o[43] = K.dpos0.y; o[44] = K.dpos0.z; o[45] = K.dpos1.x; o[46] = K.dpos1.y; o[47] = K.dpos1.z; o[48] = K.dpos2.x; o[49] = K.dpos2.y; o[50] = K.dpos2.z;
-    o[51] = 0.f;
-}
 
 // pose of link l from its (already computed) parent and its joint coordinates; also the world axes of its dofs
 template <class KC>
@@ -277,10 +203,6 @@ __global__ void __launch_bounds__(64) k_kinematics(DevModel m, DevState s) {
         for (int i = 0; i < 3 * m.nlink; i++) s.xpos[(size_t)i * N + e] = tl[s.kstride + i];
         for (int i = 0; i < 9 * m.nlink; i++) s.xmat[(size_t)i * N + e] = tl[s.kstride + 3 * m.nlink + i];
         for (int i = 0; i < 6 * m.nlink; i++) s.lvel[(size_t)i * N + e] = tl[s.kstride + 12 * m.nlink + i];
-    }
-    if (s.want_soa_kin && live) {   // only the one-lane-per-env fallback solver reads the struct-of-arrays copies
-        for (int i = 0; i < 3 * m.nv; i++) { s.dof_ang[(size_t)i * N + e] = tl[i]; s.dof_lin[(size_t)i * N + e] = tl[3 * m.nv + i]; s.dof_anchor[(size_t)i * N + e] = tl[6 * m.nv + i]; }
-        for (int i = 0; i < 15 * m.nlink; i++) s.link_dyn[(size_t)i * N + e] = tl[9 * m.nv + i];
     }
 }
 
@@ -548,7 +470,6 @@ __device__ __forceinline__ void collide_box_box_p(const Geom &G1, const Geom &G2
 }
 #undef POLY
 __device__ __forceinline__ void collide_box_box(const Geom &G1, const Geom &G2, ContactOut &out, float *poly, int lane) { collide_box_box_p(G1, G2, out, poly, 64, lane); }
-__device__ __forceinline__ void collide_box_box_slot(const Geom &G1, const Geom &G2, ContactOut &out, float *slot) { collide_box_box_p(G1, G2, out, slot, 1, 0); }
 
 // --- box-box for an 8-lane sub-group (all 8 lanes hold the same pair): the same routine as collide_box_box_p, element for
 // element, with the expensive parts spread over the lanes: the nine edge-edge axes are evaluated one per lane and folded in
@@ -899,63 +820,6 @@ __device__ __forceinline__ bool obb_overlap(const Geom &A, const Geom &B) {
             sep |= fabsf(ta[i2] * C[i1][j] - ta[i1] * C[i2][j]) > ra + rb;
         }
     return !sep;
-}
-
-// world placement of geom gi (16 floats: pos3 mat9 box-centre3 -) from the link poses; rec = DevModel::geom_rec + 32 gi
-__device__ __forceinline__ void geom_place(const float *rec, View xpos, View xmat, float *out) {
-    const int l = (int)rec[0];
-    const m3 R = xmat.getm(l);
-    m3 lm;
-#pragma unroll
-    for (int k = 0; k < 9; k++) lm.a[k] = rec[5 + k];
-    const v3 pos = xpos.get3(l) + mulmv(R, mk3(rec[2], rec[3], rec[4]));
-    const m3 mat = mulmm(R, lm);
-    const v3 bc = pos + mulmv(mat, mk3(rec[17], rec[18], rec[19]));
-    out[0] = pos.x; out[1] = pos.y; out[2] = pos.z;
-#pragma unroll
-    for (int k = 0; k < 9; k++) out[3 + k] = mat.a[k];
-    out[12] = bc.x; out[13] = bc.y; out[14] = bc.z;
-}
-// Geom from its cached world placement w (LDS) and its constant record
-__device__ __forceinline__ Geom geom_cached(const float *w, const float *rec, const float4 *mesh_vert4) {
-    Geom G;
-    G.pos = mk3(w[0], w[1], w[2]);
-#pragma unroll
-    for (int k = 0; k < 9; k++) G.mat.a[k] = w[3 + k];
-    G.bc = mk3(w[12], w[13], w[14]);
-    G.type = (int)rec[1];
-    G.size = mk3(rec[14], rec[15], rec[16]);
-    G.bh = mk3(rec[20], rec[21], rec[22]);
-    G.nvert = (int)rec[23];
-    G.verts = mesh_vert4 + (int)rec[24];
-    return G;
-}
-// the culls of pair_cull_r split in two: bounding spheres (positions only), then oriented boxes
-__device__ __forceinline__ bool pair_cull_sphere(int type1, const float *w1, const float *w2, float rb1, float rb2) {
-    const v3 r = mk3(w2[0] - w1[0], w2[1] - w1[1], w2[2] - w1[2]);
-    if (type1 == GEOM_PLANE) return dot(r, mk3(w1[5], w1[8], w1[11])) <= rb2;
-    const float b = rb1 + rb2;
-    return dot(r, r) <= b * b;
-}
-__device__ __forceinline__ bool pair_cull_box(const Geom &G1, const Geom &G2, float rb1, float rb2) {
-    if (G1.type == GEOM_PLANE) {
-        const v3 n = col(G1.mat, 2);
-        return dot(G2.bc - G1.pos, n) - (fabsf(dot(n, col(G2.mat, 0))) * G2.bh.x + fabsf(dot(n, col(G2.mat, 1))) * G2.bh.y + fabsf(dot(n, col(G2.mat, 2))) * G2.bh.z) <= 0.f;
-    }
-    if (!(sphere_hits_obb(G2.pos, rb2, G1) && sphere_hits_obb(G1.pos, rb1, G2))) return false;
-    return obb_overlap(G1, G2);
-}
-__device__ __forceinline__ bool pair_cull_r(const Geom &G1, const Geom &G2, float rb1, float rb2) {
-    if (G1.type == GEOM_PLANE) {
-        const v3 n = col(G1.mat, 2);
-        if (!(dot(G2.pos - G1.pos, n) <= rb2)) return false;
-        return dot(G2.bc - G1.pos, n) - (fabsf(dot(n, col(G2.mat, 0))) * G2.bh.x + fabsf(dot(n, col(G2.mat, 1))) * G2.bh.y + fabsf(dot(n, col(G2.mat, 2))) * G2.bh.z) <= 0.f;
-    }
-    const v3 r = G2.pos - G1.pos;
-    const float b = rb1 + rb2;
-    if (!(dot(r, r) <= b * b)) return false;
-    if (!(sphere_hits_obb(G2.pos, rb2, G1) && sphere_hits_obb(G1.pos, rb1, G2))) return false;
-    return obb_overlap(G1, G2);
 }
 
 // ---- two-stage collision: cull + compaction, then dense narrowphase ------------------------------------------------

@@ -16,7 +16,6 @@
 #include "../../include/hsrsim.h"
 #include "collide.h"
 #include "model.h"
-#include "solve.h"
 #include "solve_g.h"
 #include "solve_mf.h"
 #include "persist.h"
@@ -133,14 +132,22 @@ extern "C" int hsr_model_load(const void *blob, size_t len, hsr_model **out) {
 }
 extern "C" void hsr_model_destroy(hsr_model *m) { delete m; }
 extern "C" int hsr_model_size(const hsr_model *m, int which) { return (m && which >= 0 && which < 16) ? m->sizes[which] : HSR_EINVAL; }
-extern "C" double hsr_model_timestep(const hsr_model *m) { return m->opt[0]; }
-extern "C" int hsr_model_ctrlrange(const hsr_model *m, float *out) { memcpy(out, m->ctrlrange.data(), m->ctrlrange.size() * sizeof(float)); return HSR_OK; }
-extern "C" int hsr_model_qpos0(const hsr_model *m, float *out) { memcpy(out, m->qpos0.data(), m->qpos0.size() * sizeof(float)); return HSR_OK; }
+extern "C" double hsr_model_timestep(const hsr_model *m) { return m ? m->opt[0] : 0.0; }
+extern "C" int hsr_model_ctrlrange(const hsr_model *m, float *out) {
+    if (!m || !out) return fail(HSR_EINVAL, "null argument");
+    memcpy(out, m->ctrlrange.data(), m->ctrlrange.size() * sizeof(float)); return HSR_OK;
+}
+extern "C" int hsr_model_qpos0(const hsr_model *m, float *out) {
+    if (!m || !out) return fail(HSR_EINVAL, "null argument");
+    memcpy(out, m->qpos0.data(), m->qpos0.size() * sizeof(float)); return HSR_OK;
+}
 extern "C" int hsr_model_body_id(const hsr_model *m, const char *name) {
+    if (!m || !name) return fail(HSR_EINVAL, "null argument");
     for (size_t i = 0; i < m->body_names.size(); i++) if (m->body_names[i] == name) return (int)i;
     return fail(HSR_ENAME, "unknown body '%s'", name);
 }
 extern "C" int hsr_model_joint_qpos_addr(const hsr_model *m, const char *name, int *start, int *end) {
+    if (!m || !name || !start || !end) return fail(HSR_EINVAL, "null argument");
     for (size_t i = 0; i < m->joint_names.size() && i < m->joint_qposadr.size(); i++)
         if (m->joint_names[i] == name) { *start = m->joint_qposadr[i].first; *end = m->joint_qposadr[i].first + m->joint_qposadr[i].second; return HSR_OK; }
     return fail(HSR_ENAME, "unknown joint '%s'", name);
@@ -162,16 +169,13 @@ struct hsr_batch {
     size_t stage_floats = 0;
     uint8_t *d_stage_u8 = nullptr;
     int32_t *d_stage_i32 = nullptr;
-    int hot_threads = 64;
-    size_t hot_lds_bytes = 0;
     int narrow_blocks = 2048;      // persistent-style grid of k_narrow (HSR_NARROW_BLOCKS overrides)
     int pairs_per_wave = 4;        // k_collide: pairs walked by one wave (HSR_PPW overrides)
-    int solver = 1;                // 0: one lane per env (solve.h), 1: lane group per env (solve_g.h)
-    int group = 16;
-    size_t group_lds_bytes = 0, mf_lds_bytes = 0, persist_lds_bytes = 0;
+    int group = 16;                // lanes per env of the cooperative solver
+    size_t mf_lds_bytes = 0, persist_lds_bytes = 0;
     bool persist = false;          // whole env-step in one persistent kernel (k_env_step_mf); HSR_PERSIST=0 disables
     bool persist_ok = false;       // the model fits the persistent kernel (lane maps, LDS, kinematic structure): set once at creation
-    bool use_graph = true, profiling = false;
+    bool use_graph = true, profiling = false, debug_store = false;
     std::map<GraphKey, hipGraphExec_t> graphs;
     float last_total_ms = 0, last_kernel_ms[3] = {0, 0, 0};
     int last_launches[3] = {0, 0, 0};
@@ -180,7 +184,7 @@ struct hsr_batch {
 };
 
 // the persistent kernel instantiations: (lanes per env, compile-time bound on nv)
-typedef void (*persist_fn)(const DevModel *, DevState, int, int, float);
+typedef void (*persist_fn)(const DevModel *, DevState, int, int, float, int);
 static persist_fn persist_kernel(int group, int nv) {
     if (group == 16) return nv == 2 ? k_env_step_mf<16, 2, true> : (nv == 8 ? k_env_step_mf<16, 8, true> : (nv == 13 ? k_env_step_mf<16, 13, true> : k_env_step_mf<16, 16, false>));
     return nv == 25 ? k_env_step_mf<32, 25, true> : k_env_step_mf<32, 32, false>;
@@ -370,6 +374,7 @@ __global__ void k_expand_M(DevState s, float *out, int nv) {   // packed [nM][N]
 
 static inline dim3 grid1(size_t n, int t = 256) { return dim3((unsigned)((n + t - 1) / t)); }
 
+static int batch_init(hsr_batch *b, const hsr_model *m, int n_envs);
 extern "C" int hsr_batch_create(const hsr_model *m, int n_envs, int device_id, hsr_batch **out) {
     if (!m || !out || n_envs <= 0) return fail(HSR_EINVAL, "bad arguments to hsr_batch_create");
     int ndev = 0;
@@ -378,6 +383,12 @@ extern "C" int hsr_batch_create(const hsr_model *m, int n_envs, int device_id, h
     HIPCHK(hipSetDevice(device_id));
     hsr_batch *b = new hsr_batch();
     b->model = m; b->N = n_envs; b->device = device_id;
+    const int rc = batch_init(b, m, n_envs);
+    if (rc) { hsr_batch_destroy(b); return rc; }       // frees the stream, the events and every allocation made so far
+    *out = b;
+    return HSR_OK;
+}
+static int batch_init(hsr_batch *b, const hsr_model *m, int n_envs) {
     HIPCHK(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
     DevModel &d = b->dm;
     const int *sz = m->sizes;
@@ -494,32 +505,16 @@ extern "C" int hsr_batch_create(const hsr_model *m, int n_envs, int device_id, h
 #define DA(field, rows) if ((rc = dalloc(b, &s.field, (size_t)(rows) * N))) return rc;
     DA(qpos, d.nq) DA(qvel, d.nv) DA(ctrl, d.nu) DA(mocap, 3) DA(warm, d.nv) DA(time, 1)
     DA(done, 1) DA(bad, 1) DA(nsteps, 1)
-    DA(xpos, 3 * d.nlink) DA(xmat, 9 * d.nlink) DA(lvel, 6 * d.nlink) DA(dof_ang, 3 * d.nv) DA(dof_lin, 3 * d.nv) DA(dof_anchor, 3 * d.nv) DA(link_dyn, 15 * d.nlink)
+    DA(xpos, 3 * d.nlink) DA(xmat, 9 * d.nlink) DA(lvel, 6 * d.nlink)
     s.kstride = (9 * d.nv + 15 * d.nlink + 15) & ~15;
     DA(kin_aos, s.kstride)
     DA(con, 8 * d.nslot) DA(ncon_pair, d.npair_pad) DA(sepax, 4 * std::max(d.npair, 1)) DA(pair_list, std::max(d.npair, 1))
     if ((rc = dalloc(b, &s.pair_count, (size_t)d.npair_pad))) return rc;
     DA(M, d.nM) DA(qacc, d.nv) DA(qacc_smooth, d.nv) DA(qfrc_smooth, d.nv) DA(qfrc_constraint, d.nv)
     DA(ncon, 1) DA(nefc, 1) DA(niter, 1)
-    // solver workspace rows
-    int o = 0;
-    s.o_lw = o; o += 3 * d.nlink; s.o_lvo = o; o += 3 * d.nlink; s.o_lal = o; o += 3 * d.nlink; s.o_lao = o; o += 3 * d.nlink;
-    s.o_J = o; o += d.njmax * d.nv;
-    s.o_D = o; o += d.njmax; s.o_aref = o; o += d.njmax; s.o_jar = o; o += d.njmax; s.o_jv = o; o += d.njmax; s.o_gr = o; o += d.njmax;
-    s.o_cpair = o; o += d.nconmax; s.o_cmu = o; o += d.nconmax;
-    s.o_T = o; o += 6 * d.nv;
-    s.hot_floats = 2 * d.nM + 8 * d.nv;
-    s.o_hot = o; o += s.hot_floats;
-    s.ws_floats = o;
-    DA(ws, o)
 #undef DA
     if ((rc = dalloc(b, &s.phase_cyc, 32 + 40 * 8192))) return rc;
-    b->hot_threads = 64;
-    b->hot_lds_bytes = (size_t)s.hot_floats * 64 * sizeof(float);
-    s.hot_in_lds = b->hot_lds_bytes <= 150 * 1024 ? 1 : 0;
-    if (!s.hot_in_lds) b->hot_lds_bytes = 0;
-    else if (b->hot_lds_bytes > 64 * 1024)
-        HIPCHK(hipFuncSetAttribute((const void *)k_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->hot_lds_bytes));
+    if ((rc = dalloc(b, &s.capstat, 4))) return rc;
     // cooperative solver geometry: 16 lanes per env when nv <= 16, else 32
     b->group = d.nv <= 16 ? 16 : 32;
     {
@@ -527,28 +522,19 @@ extern "C" int hsr_batch_create(const hsr_model *m, int n_envs, int device_id, h
         if (nbk && atoi(nbk) > 0) b->narrow_blocks = atoi(nbk);
         const char *ppw = getenv("HSR_PPW");
         if (ppw && atoi(ppw) > 0) b->pairs_per_wave = atoi(ppw);
-        const char *sv = getenv("HSR_SOLVER");
-        b->solver = (sv && strcmp(sv, "v1") == 0) ? 0 : ((sv && strcmp(sv, "g") == 0) ? 1 : 2);   // default: matrix-free
-        if (d.nv > 32 || d.nlink > NLMAX || d.nconmax > b->group) b->solver = 0;
-        const int total = b->group == 16 ? SolveLayout<16>(d.njmax).total : SolveLayout<32>(d.njmax).total;
-        if (!(b->group == 16 ? SolveLayout<16>(d.njmax).fits(b->ds.kstride) : SolveLayout<32>(d.njmax).fits(b->ds.kstride)) || b->ds.kstride > 8 * 4 * b->group) b->solver = 0;
-        b->group_lds_bytes = (size_t)total * (64 / b->group) * sizeof(float);
-        if (b->group_lds_bytes > 160 * 1024) b->solver = 0;
-        if (b->solver && b->group_lds_bytes > 48 * 1024) {
-            if (b->group == 16) HIPCHK(hipFuncSetAttribute((const void *)k_solve_g<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->group_lds_bytes));
-            else HIPCHK(hipFuncSetAttribute((const void *)k_solve_g<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->group_lds_bytes));
-        }
     }
-    if (b->solver == 2) {
+    if (d.nv > 32 || d.nq > 64 || d.nlink > NLMAX || d.nconmax > b->group || b->ds.kstride > 8 * 4 * b->group)
+        return fail(HSR_EINVAL, "model exceeds the lane-group solver (nv <= 32, nlink <= 16, nconmax <= lanes per env)");
+    {
         const int total = b->group == 16 ? MfLayout<16>(d.njmax, b->ds.kstride).total : MfLayout<32>(d.njmax, b->ds.kstride).total;
         b->mf_lds_bytes = (size_t)total * (64 / b->group) * sizeof(float);
-        if (b->ds.kstride > 8 * 4 * b->group || b->mf_lds_bytes > 160 * 1024) b->solver = 1;
-        else if (b->mf_lds_bytes > 48 * 1024) {
+        if (b->mf_lds_bytes > 160 * 1024) return fail(HSR_EINVAL, "model exceeds the LDS budget of the solver");
+        if (b->mf_lds_bytes > 48 * 1024) {
             if (b->group == 16) HIPCHK(hipFuncSetAttribute((const void *)k_solve_mf<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->mf_lds_bytes));
             else HIPCHK(hipFuncSetAttribute((const void *)k_solve_mf<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->mf_lds_bytes));
         }
     }
-    if (b->solver == 2) {
+    {
         const int total = b->group == 16 ? PersistLayout<16>(d.njmax, b->ds.kstride, d.npair_pad, d.nlink, d.ngeom, d.nstatic_geom).total : PersistLayout<32>(d.njmax, b->ds.kstride, d.npair_pad, d.nlink, d.ngeom, d.nstatic_geom).total;
         b->persist_lds_bytes = (size_t)total * sizeof(float);
         // what the persistent kernel's lane maps and kinematics assume (kin2.h, persist.h); a model outside it runs the per-substep chain
@@ -569,23 +555,13 @@ extern "C" int hsr_batch_create(const hsr_model *m, int n_envs, int device_id, h
         if (ok && b->persist_lds_bytes > 48 * 1024)
             HIPCHK(hipFuncSetAttribute((const void *)persist_kernel(b->group, d.nv), hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->persist_lds_bytes));
     }
-    if (getenv("HSR_DEBUG")) {
-        int nb = -1;
-        if (b->solver == 2 && b->group == 16) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_solve_mf<16>, 64, b->mf_lds_bytes);
-        else if (b->solver == 1 && b->group == 16) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_solve_g<16>, 64, b->group_lds_bytes);
-        hipFuncAttributes fa;
-        if (b->solver == 2 && b->group == 16 && hipFuncGetAttributes(&fa, (const void *)k_solve_mf<16>) == hipSuccess)
-            fprintf(stderr, "[hsrsim] k_solve_mf<16>: regs %d, static LDS %zu, dyn LDS %zu, scratch %zu, maxThreads %d\n", fa.numRegs, fa.sharedSizeBytes, b->mf_lds_bytes, fa.localSizeBytes, fa.maxThreadsPerBlock);
-        fprintf(stderr, "[hsrsim] solver %d group %d: occupancy API says %d workgroups per CU\n", b->solver, b->group, nb);
-        if (b->persist && b->group == 16) {
-            int pb = -1;
-            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&pb, persist_kernel(b->group, d.nv), 64, b->persist_lds_bytes);
-            hipFuncAttributes fb;
-            if (hipFuncGetAttributes(&fb, (const void *)persist_kernel(b->group, d.nv)) == hipSuccess)
-                fprintf(stderr, "[hsrsim] k_env_step_mf<16>: regs %d, static LDS %zu, dyn LDS %zu, scratch %zu -> %d workgroups per CU\n", fb.numRegs, fb.sharedSizeBytes, b->persist_lds_bytes, fb.localSizeBytes, pb);
-        }
+    if (getenv("HSR_DEBUG") && b->persist_ok) {
+        int pb = -1;
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&pb, persist_kernel(b->group, d.nv), 64, b->persist_lds_bytes);
+        hipFuncAttributes fb;
+        if (hipFuncGetAttributes(&fb, (const void *)persist_kernel(b->group, d.nv)) == hipSuccess)
+            fprintf(stderr, "[hsrsim] k_env_step_mf<%d>: regs %d, static LDS %zu, dyn LDS %zu, scratch %zu -> %d workgroups per CU\n", b->group, fb.numRegs, fb.sharedSizeBytes, b->persist_lds_bytes, fb.localSizeBytes, pb);
     }
-    b->ds.want_soa_kin = b->solver == 0 ? 1 : 0;
     {
         const size_t kb = (size_t)64 * (b->ds.kstride + 24 * d.nlink + 1) * sizeof(float);
         if (kb > 160 * 1024) return fail(HSR_EINVAL, "kinematics tile exceeds LDS");
@@ -604,20 +580,19 @@ extern "C" int hsr_batch_create(const hsr_model *m, int n_envs, int device_id, h
     b->d_qpos0 = d_q0;
     hipLaunchKernelGGL(k_reset, grid1(N), dim3(256), 0, b->stream, b->dm, b->ds, (const uint8_t *)nullptr, (const float *)nullptr, (const float *)d_q0, (const float *)nullptr);
     HIPCHK(hipStreamSynchronize(b->stream));
-    *out = b;
     return HSR_OK;
 }
 
 extern "C" void hsr_batch_destroy(hsr_batch *b) {
     if (!b) return;
     hipSetDevice(b->device);
-    hipStreamSynchronize(b->stream);
+    if (b->stream) hipStreamSynchronize(b->stream);
     for (auto &kv : b->graphs) hipGraphExecDestroy(kv.second);
     for (void *p : b->allocs) hipFree(p);
     for (hipEvent_t ev : b->kev) hipEventDestroy(ev);
     if (b->ev0) hipEventDestroy(b->ev0);
     if (b->ev1) hipEventDestroy(b->ev1);
-    hipStreamDestroy(b->stream);
+    if (b->stream) hipStreamDestroy(b->stream);
     delete b;
 }
 extern "C" int hsr_batch_size(const hsr_batch *b) { return b->N; }
@@ -639,6 +614,15 @@ extern "C" int hsr_batch_set_persistent(hsr_batch *b, int on) {
     return b->persist ? 1 : 0;
 }
 extern "C" int hsr_batch_is_persistent(const hsr_batch *b) { return b->persist ? 1 : 0; }
+extern "C" int hsr_batch_set_debug(hsr_batch *b, int on) { b->debug_store = on != 0; return HSR_OK; }
+extern "C" int hsr_batch_cap_counts(hsr_batch *b, unsigned long long *out) {
+    if (!b || !out) return fail(HSR_EINVAL, "null argument");
+    HIPCHK(hipSetDevice(b->device));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    HIPCHK(hipMemcpy(out, b->ds.capstat, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemset(b->ds.capstat, 0, 4 * sizeof(unsigned long long)));
+    return HSR_OK;
+}
 
 // one substep = 3 launches on the batch stream
 static void launch_substep(hsr_batch *b, int mode, int goal_body, float geofence, int debug, hipStream_t st, bool timed) {
@@ -652,11 +636,8 @@ static void launch_substep(hsr_batch *b, int mode, int goal_body, float geofence
         hipLaunchKernelGGL(k_narrow, dim3(b->narrow_blocks), dim3(64), 0, st, b->dm, b->ds);
     }
     rec();
-    if (b->solver == 0) hipLaunchKernelGGL(k_solve, dim3((N + 63) / 64), dim3(64), b->hot_lds_bytes, st, b->dm, b->ds, mode, goal_body, geofence, debug);
-    else if (b->solver == 2 && b->group == 16) hipLaunchKernelGGL(k_solve_mf<16>, dim3((N + 3) / 4), dim3(64), b->mf_lds_bytes, st, b->dm, b->ds, mode, goal_body, geofence, debug);
-    else if (b->solver == 2) hipLaunchKernelGGL(k_solve_mf<32>, dim3((N + 1) / 2), dim3(64), b->mf_lds_bytes, st, b->dm, b->ds, mode, goal_body, geofence, debug);
-    else if (b->group == 16) hipLaunchKernelGGL(k_solve_g<16>, dim3((N + 3) / 4), dim3(64), b->group_lds_bytes, st, b->dm, b->ds, mode, goal_body, geofence, debug);
-    else hipLaunchKernelGGL(k_solve_g<32>, dim3((N + 1) / 2), dim3(64), b->group_lds_bytes, st, b->dm, b->ds, mode, goal_body, geofence, debug);
+    if (b->group == 16) hipLaunchKernelGGL(k_solve_mf<16>, dim3((N + 3) / 4), dim3(64), b->mf_lds_bytes, st, b->dm, b->ds, mode, goal_body, geofence, debug);
+    else hipLaunchKernelGGL(k_solve_mf<32>, dim3((N + 1) / 2), dim3(64), b->mf_lds_bytes, st, b->dm, b->ds, mode, goal_body, geofence, debug);
     rec();
 }
 
@@ -762,7 +743,7 @@ extern "C" int hsr_batch_step_dev(hsr_batch *b, const float *d_ctrl, int n_subst
             if (rc2) return rc2;
             HIPCHK(hipMemcpy(b->d_dm, &b->dm, sizeof(DevModel), hipMemcpyHostToDevice));
         }
-        hipLaunchKernelGGL(persist_kernel(b->group, b->dm.nv), dim3((N + epb - 1) / epb), dim3(64), b->persist_lds_bytes, st, (const DevModel *)b->d_dm, b->ds, n_substeps, goal_body, geofence);
+        hipLaunchKernelGGL(persist_kernel(b->group, b->dm.nv), dim3((N + epb - 1) / epb), dim3(64), b->persist_lds_bytes, st, (const DevModel *)b->d_dm, b->ds, n_substeps, goal_body, geofence, b->debug_store ? 1 : 0);
         if (b->profiling) { hipEvent_t ev; hipEventCreate(&ev); hipEventRecord(ev, st); b->kev.push_back(ev); }   // slots 0,1 empty; slot 2 = the persistent kernel
     } else if (b->use_graph && !b->profiling && n_substeps > 0) {
         GraphKey key{n_substeps, goal_body, geofence};

@@ -42,13 +42,11 @@ struct DevState {
     float *qpos, *qvel, *ctrl, *mocap, *warm, *time;
     int *done, *bad, *nsteps;
     // kinematics outputs
-    float *xpos, *xmat, *dof_ang, *dof_lin, *dof_anchor;
+    float *xpos, *xmat;
     float *lvel;                      // [6 nlink][N] angular velocity, linear velocity of the link origin: same forward pass as xpos (obs kernel)
-    // per-link dynamics terms from the kinematics kernel: com(3) Iworld(6: xx yy zz xy xz yz) F(3) N(3)
-    float *link_dyn;
     // env-major copy of the solver's kinematic inputs: kin_aos[e][kstride] = ang[3nv] lin[3nv] anchor[3nv] link_dyn[15 nlink]
     float *kin_aos;
-    int kstride, want_soa_kin;
+    int kstride;
     // collision outputs, env-major so that one env's lane group reads them coalesced:
     //   con[(e * nslot + slot) * 8 + k]  (pos 0-2, normal 3-5, dist 6), ncon_pair[e * npair_pad + p]
     float *con;
@@ -59,12 +57,6 @@ struct DevState {
     // dynamics / solver outputs kept for introspection
     float *M, *qacc, *qacc_smooth, *qfrc_smooth, *qfrc_constraint;
     int *ncon, *nefc, *niter;
-    // solver workspace: [ws_floats][N]
-    float *ws;
-    int ws_floats;
-    // offsets (in rows) into ws
-    int o_lw, o_lvo, o_lal, o_lao, o_J, o_D, o_aref, o_jar, o_jv, o_gr, o_cpair, o_cmu, o_T, o_hot;
-    int hot_floats;      // rows of the "hot" per-thread block (M, H, vectors); lives in LDS when it fits
-    int hot_in_lds;
+    unsigned long long *capstat;     // [4] cap statistics (include/hsrsim.h: hsr_batch_cap_counts)
     unsigned long long *phase_cyc;   // diagnostic build only (HSR_PHASE_TIMING): per-phase cycle sums
 };

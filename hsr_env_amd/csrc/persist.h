@@ -43,7 +43,7 @@ template <int G> struct PersistLayout {
 // NVT: compile-time bound on nv (nv <= NVT <= G); the matrix loops of the solver run to NVT instead of G
 // EXACT: nv == NVT, known at compile time (the `j < nv` guards of the unrolled matrix loops fold away)
 template <int G, int NVT, bool EXACT>
-__global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restrict__ mp, DevState s, int n_substeps, int goal_body, float geofence) {
+__global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restrict__ mp, DevState s, int n_substeps, int goal_body, float geofence, int flags) {
     // the ~90 model fields stay in (constant-cached) memory and are read where they are used, instead of sitting in - and
     // spilling from - SGPRs for the whole launch
     const DevModel &m = *mp;
@@ -53,6 +53,8 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
     const int tid0 = threadIdx.x;
     const int N = s.N, nv = EXACT ? NVT : m.nv, nq = m.nq, R = L.R, MS = L.MS;
     const int mode = 1, debug = 0;
+    const bool dbg_store = flags & 1;          // introspection: contact counts / solver counters of each env's last substep go to global memory
+    int cap_con = 0, cap_row = 0, cap_item = 0, nsub_run = 0;      // cap statistics of this lane's env (lane c == 0 reports)
     // everything derived from the lane id is declared through this macro: once for the prologue, once per substep from a
     // laundered copy of the lane id (so that LLVM does not hoist ~100 loop-invariant addresses out of the substep loop and
     // then spill them), once for the epilogue
@@ -311,7 +313,7 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
             wave_sync();
             PHASE(19);
 #pragma unroll
-            for (int j = 0; j < EPB; j++) if (g == j && nit_env[j] > 64) bad = 1;      // more than 64 surviving pairs in ONE env: its contacts beyond them are dropped
+            for (int j = 0; j < EPB; j++) if (g == j && nit_env[j] > 64) { bad = 1; cap_item += valid ? 1 : 0; }      // more than 64 surviving pairs in ONE env: its contacts beyond them are dropped
             DBGCNT(2, nitems);
             wave_sync();
             for (int ib = 0; ib < nitems; ib += 64) {
@@ -414,6 +416,7 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
         }
         __threadfence_block();       // contact records written to global by other lanes of this workgroup
         __syncthreads();
+        if (dbg_store && valid) for (int p = c; p < m.npair; p += G) s.ncon_pair[(size_t)e * m.npair_pad + p] = pcnt[p];
         PHASE(17);
         // ---------------- S: dynamics + constraint solve + Euler (shared body)
         // per-dof view of qpos (scalar joints: their own coordinate; free joints: lin dofs their coordinate)
@@ -427,10 +430,12 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
         float *lvbuf = reinterpret_cast<float *>(pcnt);       // the pair counts are consumed by the contact compaction (E2), before the first J v
         const int lvcap = ((m.npair_pad + 3) / 4) / 6;
         {
-#define SOLVE_STORE_DIAG false
+#define SOLVE_STORE_DIAG dbg_store
+#define SOLVE_COUNT_CAPS 1
 #define PAIR_CNT(p) pcnt[p]
 #include "solve_body.inc"
 #undef PAIR_CNT
+#undef SOLVE_COUNT_CAPS
 #undef SOLVE_STORE_DIAG
             // ---------------- integrate (a-2.7) in registers; qpos is redistributed through LDS (lane = qpos index)
             const float v1 = __shfl_down(vnew, 1, G), v2 = __shfl_down(vnew, 2, G);
@@ -457,7 +462,7 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
             if (valid) {
                 if (c < nq) qpos_c = qn[c];
                 qvel_c = vnew; warm_c = qacc_c;
-                time_e += h; nsteps_e += 1;
+                time_e += h; nsteps_e += 1; nsub_run += 1;
                 if (bad) bad_acc = 1;
                 if (reach) done = true;          // a-4: latch; the env skips the remaining substeps
             }
@@ -473,6 +478,10 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
         if (isdof) { s.qvel[(size_t)c * N + e] = qvel_c; s.warm[(size_t)c * N + e] = warm_c; }
         const float bsum = gsum<G>((float)bad_acc);
         if (c == 0) {
+            if (cap_con) atomicAdd(&s.capstat[0], (unsigned long long)cap_con);
+            if (cap_row) atomicAdd(&s.capstat[1], (unsigned long long)cap_row);
+            if (cap_item) atomicAdd(&s.capstat[2], (unsigned long long)cap_item);
+            atomicAdd(&s.capstat[3], (unsigned long long)nsub_run);
             s.time[e] = time_e; s.nsteps[e] = s.nsteps[e] + nsteps_e;
             if (bsum > 0) s.bad[e] = 1;
             if (done) s.done[e] = 1;

@@ -27,31 +27,6 @@ def distance_between(pos1, pos2):                        # hsr/env.py:231-232
     return np.sqrt(np.sum(np.square(pos1 - pos2), axis=-1))
 
 
-def quaternion2euler(w, x, y, z):                        # hsr/env.py:212-228
-    ysqr = y * y
-    t0 = +2.0 * (w * x + y * z)
-    t1 = +1.0 - 2.0 * (x * x + ysqr)
-    euler_x = np.arctan2(t0, t1)
-    t2 = np.clip(+2.0 * (w * y - z * x), -1, 1)
-    euler_y = np.arcsin(t2)
-    t3 = +2.0 * (w * z + x * y)
-    t4 = +1.0 - 2.0 * (ysqr + z * z)
-    euler_z = np.arctan2(t3, t4)
-    return euler_x, euler_y, euler_z
-
-
-def mat2euler(mat):                                      # hsr/env.py:256-272
-    mat = np.asarray(mat, dtype=np.float64)
-    assert mat.shape[-2:] == (3, 3), "Invalid shape matrix {}".format(mat)
-    cy = np.sqrt(mat[..., 2, 2] * mat[..., 2, 2] + mat[..., 1, 2] * mat[..., 1, 2])
-    condition = cy > np.finfo(np.float64).eps * 4.
-    euler = np.empty(mat.shape[:-1], dtype=np.float64)
-    euler[..., 2] = np.where(condition, -np.arctan2(mat[..., 0, 1], mat[..., 0, 0]), -np.arctan2(-mat[..., 1, 0], mat[..., 1, 1]))
-    euler[..., 1] = np.where(condition, -np.arctan2(-mat[..., 0, 2], cy), -np.arctan2(-mat[..., 0, 2], cy))
-    euler[..., 0] = np.where(condition, -np.arctan2(mat[..., 1, 2], mat[..., 2, 2]), 0.0)
-    return euler
-
-
 def block_space_to_qpos(sample4: np.ndarray) -> np.ndarray:
     """(x, y, z, yaw) of a block -> free-joint qpos (x y z qw qx qy qz); the build's reading of
     ``--block-space`` (a Box(4), hsr/util.py:33), see SURVEY.md section 8(a) defects."""
@@ -208,6 +183,12 @@ class VecHSREnv:
         steps = steps or self.steps_per_action
         goal_body = self._goal_body if self.goals else -1
         obs, rew, done, ns = self.sim.step(action, steps, goal_body, self._geofence)
+        bad_state = getattr(self.sim, "bad_state", None)
+        if bad_state is not None:
+            bad, any_bad = bad_state()
+            if any_bad:                                                 # mujoco_py.MujocoException on MuJoCo's divergence warnings
+                from .sim import MujocoException
+                raise MujocoException(f"simulation diverged in env(s) {np.flatnonzero(bad)[:8].tolist()} (non-finite or |q| > 1e10)")
         self._time_steps += 1
         if self._obs_type == "openai":
             obs = self.sim.obs_openai()

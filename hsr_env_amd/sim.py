@@ -36,7 +36,8 @@ EXPORTS = [
     "hsr_batch_set_warmstart", "hsr_batch_get_warmstart", "hsr_batch_forward", "hsr_batch_step",
     "hsr_batch_step_dev", "hsr_batch_body_xpos", "hsr_batch_bad_state", "hsr_batch_get_field",
     "hsr_batch_set_profiling", "hsr_batch_last_timing", "hsr_batch_set_graph", "hsr_batch_set_persistent", "hsr_batch_is_persistent",
-    "hsr_batch_obs_openai", "hsr_batch_obs_openai_dev",
+    "hsr_batch_obs_openai", "hsr_batch_obs_openai_dev", "hsr_batch_set_debug", "hsr_batch_cap_counts",
+    "hsr_batch_phase_cycles", "hsr_batch_block_times",
 ]
 
 F_XPOS, F_XMAT, F_M, F_QACC, F_QACC_SMOOTH, F_QFRC_SMOOTH, F_QFRC_CONSTRAINT, F_NCON, F_NEFC, F_CONTACT, F_NITER = range(11)
@@ -89,6 +90,8 @@ def load_library():
     L.hsr_batch_set_graph.argtypes = [vp, C.c_int]
     L.hsr_batch_set_persistent.argtypes = [vp, C.c_int]
     L.hsr_batch_is_persistent.argtypes = [vp]
+    L.hsr_batch_set_debug.argtypes = [vp, C.c_int]
+    L.hsr_batch_cap_counts.argtypes = [vp, C.POINTER(C.c_ulonglong)]
     _lib = L
     return L
 
@@ -250,6 +253,16 @@ class BatchSim:
 
     def is_persistent(self) -> bool:
         return bool(self._L.hsr_batch_is_persistent(self._b))
+
+    def set_debug(self, on: bool):
+        """Also store the contact counts / solver counters of each env's last substep during step() (persistent kernel)."""
+        _check(self._L, self._L.hsr_batch_set_debug(self._b, int(on)))
+
+    def cap_counts(self):
+        """(contact-cap hits, row-cap hits, item-cap hits, env-substeps executed) since the last call."""
+        out = (C.c_ulonglong * 4)()
+        _check(self._L, self._L.hsr_batch_cap_counts(self._b, out))
+        return tuple(int(x) for x in out)
 
     def last_timing(self):
         tot = C.c_float(0); k = (C.c_float * 3)(); n = (C.c_int * 3)()

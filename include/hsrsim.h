@@ -113,6 +113,15 @@ int hsr_batch_set_graph(hsr_batch *b, int on);
  * resulting setting.  With it on, hsr_batch_last_timing() reports the persistent kernel in slot 2 (slots 0,1 = 0). */
 int hsr_batch_set_persistent(hsr_batch *b, int on);
 int hsr_batch_is_persistent(const hsr_batch *b);
+/* introspection after hsr_batch_step*: with it on, the persistent kernel also stores what hsr_batch_forward stores - the
+ * per-pair contact counts (HSR_F_CONTACT), HSR_F_NCON / NEFC / NITER and HSR_F_QACC of every env's LAST substep (default off:
+ * the fields then describe the last hsr_batch_forward).  Parity tests of the hot path's own narrowphase use it. */
+int hsr_batch_set_debug(hsr_batch *b, int on);
+/* How often the device buffer caps bit since the last call (the counters are cleared): out[0] = (env, substep) pairs that
+ * dropped contacts beyond nconmax, out[1] = dropped constraint rows beyond njmax, out[2] = dropped narrowphase work items
+ * beyond 64 per env, out[3] = (env, substep) pairs executed.  MuJoCo's own caps are nconmax=100 njmax=500
+ * (hsr/models/world.xml:44); the compiled models carry smaller ones. */
+int hsr_batch_cap_counts(hsr_batch *b, unsigned long long *out /*[4]*/);
 
 /* diagnostics (meaningful only in the -DHSR_PHASE_TIMING build, libhsrsim_timing.so; tools/phase_timing.py,
  * tools/block_times.py): per-phase cycle sums of the last launches, and per-workgroup

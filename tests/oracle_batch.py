@@ -58,13 +58,24 @@ class OracleBatchSim:
         self.sims = []
 
 
+def mat2euler(mat):
+    """Checker-side restatement of the reference's rotation -> Euler convention (hsr/env.py:256-272): what k_obs_openai must
+    reproduce for the object's rotation."""
+    mat = np.asarray(mat, dtype=np.float64)
+    cy = np.hypot(mat[..., 2, 2], mat[..., 1, 2])
+    ok = cy > 4 * np.finfo(np.float64).eps
+    z = np.where(ok, -np.arctan2(mat[..., 0, 1], mat[..., 0, 0]), -np.arctan2(-mat[..., 1, 0], mat[..., 1, 1]))
+    y = -np.arctan2(-mat[..., 0, 2], cy)
+    x = np.where(ok, -np.arctan2(mat[..., 1, 2], mat[..., 2, 2]), 0.0)
+    return np.stack([x, y, z], axis=-1)
+
+
 def openai_obs_reference(m, q_fk, v_fk, q_now, v_now, finger_bodies=("hand_l_distal_link", "hand_r_distal_link"),
                          finger_joints=("hand_l_proximal_joint", "hand_r_proximal_joint"), object_body=None):
     """numpy fp64 restatement of the 'openai' observation (hsr/env.py:72-110 with the intent of SURVEY.md 8a-5): body poses
     and velocities from the forward pass at (q_fk, v_fk) (velocity of a body origin = point Jacobian x qvel, the content
     of mj_objectVelocity), joint values from the current state, dt = timestep."""
     from hsr_env_amd import compiler as hc
-    from hsr_env_amd.env import mat2euler
     dt = m.timestep
     xpos, xquat = hc.link_kinematics(m, np.asarray(q_fk, np.float64))
     ang, lin, anchor = hc.dof_motion(m, xpos, xquat, np.asarray(q_fk, np.float64))

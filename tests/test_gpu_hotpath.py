@@ -1,0 +1,225 @@
+"""GPU parity tests aimed at the branches of the hot path that the stage tests do not reach: the persistent kernel's own
+narrowphase (compared contact by contact), the ctrl / force clamps with the reference driver's actions, a --set-xml model,
+a model that must fall back to the per-substep chain, hipGraph replay of that chain, and the bad-state exception."""
+import numpy as np
+import pytest
+
+from hsr_env_amd import sim as hs
+from oracle.oracle import OracleSim
+from test_gpu_parity import oracle_rollout, random_states
+
+pytestmark = pytest.mark.gpu
+
+
+def contact_mismatch(m, slots, oc):
+    """None when the HIP contact records slots[nslot,7] (pos3 normal3 dist; dist = +1: empty) equal the oracle's oc[k,17] to fp32
+    tolerance, else a reason.  Contacts are matched pair by pair; inside a pair (box-box: up to 8 points) the order of the points
+    is free - the 8-lane clipper emits the polygon from another starting vertex than the sequential one."""
+    used = slots[:, 6] <= 0
+    if int(used.sum()) != len(oc):
+        return f"count {int(used.sum())} vs {len(oc)}"
+    for p in range(m.npair):
+        a, b = int(m.pair_slot[p]), int(m.pair_slot[p + 1])
+        gp = slots[a:b][used[a:b]]
+        op = oc[(oc[:, 13] == m.pair_geom1[p]) & (oc[:, 14] == m.pair_geom2[p])]
+        if len(gp) != len(op):
+            return f"count of pair {p}: {len(gp)} vs {len(op)}"
+        left = list(range(len(op)))
+        for g in gp:
+            k = min(left, key=lambda i: np.abs(op[i, 0:3] - g[0:3]).max())
+            left.remove(k)
+            if abs(g[6] - op[k, 12]) > 1e-5:
+                return f"depth {abs(g[6] - op[k, 12]):.2e} (pair {p})"
+            if np.abs(g[3:6] - op[k, 3:6]).max() > 2e-3:
+                return f"normal {np.abs(g[3:6] - op[k, 3:6]).max():.2e} (pair {p})"
+            if np.abs(g[0:3] - op[k, 0:3]).max() > 2e-4:
+                return f"position {np.abs(g[0:3] - op[k, 0:3]).max():.2e} (pair {p})"
+    return None
+
+
+@pytest.mark.parametrize("cfg", ["cfg2", "cfg3", "cfg4", "cupboard", "cfg3_setxml"])
+def test_persistent_contacts_match_oracle(models, cfg):
+    """The persistent kernel's OWN collision code (geom cache, sphere / box culls, separation-margin cache, 8-lane box-box and
+    MPR): after step(ctrl, 1) with the introspection flag the contact records of that substep's forward pass must equal the
+    oracle's at the same state: same count per env, depth 1e-5, normal 2e-3, position 2e-4 (the bounds of the stage test of the
+    chain kernels).  A contact at the edge of existence (|depth| < 2e-6 in either precision) may appear in one list only: such envs
+    are counted and must stay below 2 %; everything else must match exactly.  Three consecutive substeps are checked, the later
+    ones from the HIP path's own state, so that the separating-axis / margin caches are exercised fresh and carried over."""
+    m = models[cfg]
+    n = 96
+    rng = np.random.default_rng(110)
+    q, v, ctrl = random_states(m, n, rng)
+    pre = oracle_rollout(m, q, v, ctrl, 40)
+    sim = hs.BatchSim(m, n)
+    assert sim.is_persistent()
+    sim.set_debug(True)
+    sim.set_warmstart(np.array([s.qacc_warmstart for s in pre]))
+    sim.set_state(np.zeros(n), np.array([s.qpos for s in pre]), np.array([s.qvel for s in pre]))
+    states = [(np.array([s.qpos for s in pre]), np.array([s.qvel for s in pre]))]
+    for rnd in range(3):
+        sim.step(ctrl, 1)
+        ncon = sim.get_field(hs.F_NCON); con = sim.get_field(hs.F_CONTACT)
+        qs, vs = states[-1]
+        edge, reasons = 0, []
+        for e in range(n):
+            o = OracleSim(m)
+            o.qpos[:] = qs[e]; o.qvel[:] = vs[e]; o.ctrl[:] = ctrl[e]
+            o.forward()                                 # contacts of the state the HIP substep started from
+            oc = o.contacts()
+            gc = con[e][con[e][:, 6] <= 0]
+            why = contact_mismatch(m, con[e], oc)
+            if why is not None:
+                shallow = (len(oc) and np.abs(oc[:, 12]).min() < 2e-6) or (len(gc) and np.abs(gc[:, 6]).min() < 2e-6)
+                if why.startswith("count") and shallow:
+                    edge += 1
+                else:
+                    reasons.append((e, why))
+            else:
+                assert int(ncon[e]) == min(len(oc), int(m.arrays["sizes"][10]))
+        # next round: the HIP path's own state after its substep (read back as fp32), margins and separating axes carried over
+        t1, q1, v1 = sim.get_state()
+        states.append((q1.astype(np.float64), v1.astype(np.float64)))
+        print(f"{cfg} round {rnd}: {edge} edge-of-existence envs, {len(reasons)} mismatches")
+        assert not reasons, reasons[:5]
+        assert edge <= max(1, n // 50)
+    assert not sim.bad_state()[1]
+    sim.close()
+
+
+@pytest.mark.parametrize("cfg", ["cfg3", "cfg3_setxml"])
+def test_reference_driver_actions_and_clamps(models, cfg):
+    """The reference's driver sends zeros plus a mouse delta (hsr/control.py:49-62): zeros are outside arm_lift's ctrlrange
+    [2.3, 4.1] and arm_flex's [-1.2, -.5] (world.xml:112,115), +-10 is outside every range, so the ctrl clamp and the force clamp
+    of solve_body.inc run.  40 substeps against the oracle from the model's initial state: |dqpos| < 2e-5, |dqvel| < 2e-3 for every
+    env.  In cfg3_setxml the arm-lift actuator has no ctrl limit (compiler: ctrllimited=false -> infinite range)."""
+    m = models[cfg]
+    acts = np.array([np.zeros(m.nu), np.full(m.nu, 10.0), np.full(m.nu, -10.0),
+                     np.where(np.arange(m.nu) % 2 == 0, 10.0, -10.0)], dtype=np.float32)
+    n = len(acts)
+    sim = hs.BatchSim(m, n)
+    obs, rew, done, ns = sim.step(acts, 40)
+    for e in range(n):
+        o = OracleSim(m)
+        o.env_step(acts[e].astype(np.float64), 40)
+        dq = np.abs(obs[e, :m.nq] - o.qpos).max(); dv = np.abs(obs[e, m.nq:] - o.qvel).max()
+        assert dq < 2e-5 and dv < 2e-3, (cfg, e, dq, dv)
+    if cfg == "cfg3_setxml":
+        # the unlimited arm-lift actuator really is unclamped: from q = 0.3 a ctrl of 1.0 (below the limited range [2.3, 4.1], inside
+        # the force range either way) pulls the lift down, while the limited actuator of cfg3 clamps it to 2.3 and pushes up
+        q = np.tile(m.qpos0, (2, 1)).astype(np.float32); q[:, 2] = 0.3
+        c = np.zeros((2, m.nu), np.float32); c[:, 2] = 1.0; c[:, 3] = -0.8
+        res = []
+        for mm in (m, models["cfg3"]):
+            s2 = hs.BatchSim(mm, 2)
+            s2.set_state(np.zeros(2, np.float32), q, np.zeros((2, mm.nv), np.float32))
+            res.append(s2.step(c, 40)[0][0, 2])
+            s2.close()
+        o = OracleSim(m)
+        o.qpos[:] = q[0]; o.env_step(c[0].astype(np.float64), 40)
+        assert abs(res[0] - o.qpos[2]) < 2e-5 and res[0] < 0.3 - 1e-3 and res[1] > res[0] + 1e-3, (res, o.qpos[2])
+    sim.close()
+
+
+def test_setxml_model_single_substep(models):
+    """SURVEY 8f row 2 on hardware: the --set-xml model (other pan friction) through the same per-substep parity as cfg3."""
+    m = models["cfg3_setxml"]
+    n = 64
+    rng = np.random.default_rng(111)
+    q, v, ctrl = random_states(models["cfg3"], n, rng)      # cfg3's ranges (the unlimited actuator has none to sample from)
+    pre = oracle_rollout(m, q, v, ctrl, 60)
+    sim = hs.BatchSim(m, n)
+    sim.set_debug(True)
+    sim.set_warmstart(np.array([s.qacc_warmstart for s in pre]))
+    sim.set_state(np.zeros(n), np.array([s.qpos for s in pre]), np.array([s.qvel for s in pre]))
+    obs = sim.step(ctrl, 1)[0]
+    ncon = sim.get_field(hs.F_NCON)
+    unexplained = []
+    for e in range(n):
+        o = pre[e]
+        o.step()
+        dq = np.abs(obs[e, :m.nq] - o.qpos).max()
+        dv = (np.abs(obs[e, m.nq:] - o.qvel) / (1 + np.abs(o.qvel))).max()
+        if not (dq < 5e-6 and dv < 1e-4) and int(ncon[e]) == o.ncon:
+            unexplained.append((e, dq, dv))
+    assert not unexplained, unexplained
+    sim.close()
+
+
+def test_model_wider_than_its_lane_group_uses_the_chain(models):
+    """nq = 18 > 16 lanes (nv = 16): the persistent kernel holds qpos one entry per lane, so this model must run the
+    per-substep chain (which indexes qpos through dof_qposadr) - and match the oracle."""
+    m = models["nq18"]
+    assert m.nq == 18 and m.nv == 16
+    n = 48
+    rng = np.random.default_rng(112)
+    q, v, ctrl = random_states(m, n, rng)
+    sim = hs.BatchSim(m, n)
+    assert not sim.is_persistent() and not sim.set_persistent(True)
+    pre = oracle_rollout(m, q, v, ctrl, 30)
+    sim.set_warmstart(np.array([s.qacc_warmstart for s in pre]))
+    sim.set_state(np.zeros(n), np.array([s.qpos for s in pre]), np.array([s.qvel for s in pre]))
+    obs = sim.step(ctrl, 1)[0]
+    bad = 0
+    for e in range(n):
+        o = pre[e]
+        o.step()
+        dq = np.abs(obs[e, :m.nq] - o.qpos).max()
+        dv = (np.abs(obs[e, m.nq:] - o.qvel) / (1 + np.abs(o.qvel))).max()
+        bad += not (dq < 5e-6 and dv < 1e-4)
+    assert bad <= 1, bad
+    sim.close()
+
+
+def test_graph_replay_equals_plain_launches(models):
+    """The per-substep chain (fallback path) replayed from its captured hipGraph gives bit-identical results to plain launches."""
+    m = models["cfg3"]
+    n = 128
+    rng = np.random.default_rng(15)
+    q, v, ctrl = random_states(m, n, rng)
+    outs = []
+    for use_graph in (True, False):
+        sim = hs.BatchSim(m, n)
+        assert sim.set_persistent(False) is False
+        sim.set_graph(use_graph)
+        sim.set_state(np.zeros(n), q, v)
+        o1 = sim.step(ctrl, 50)[0].copy(); o2 = sim.step(ctrl, 50)[0].copy()
+        outs.append((o1, o2))
+        sim.close()
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+
+
+def test_env_raises_on_bad_state(models):
+    """mujoco_py raises MujocoException when MuJoCo warns about a diverged state; VecHSREnv.step checks the per-env flags."""
+    from hsr_env_amd.env import VecHSREnv
+    m = models["cfg2"]
+    env = VecHSREnv(model=m, n_envs=8, steps_per_action=5)
+    env.reset()
+    qpos = np.tile(m.qpos0, (8, 1)); qvel = np.zeros((8, m.nv)); qvel[3, 0] = 1e12
+    env.set_state(qpos, qvel)
+    with pytest.raises(hs.MujocoException):
+        env.step(np.zeros((8, m.nu)))
+    env.close()
+
+
+def test_cap_counters_and_full_size(models):
+    """BASELINE size, bench inputs: how often the device buffer caps (16 contacts / 48 rows / 64 items per env) bite - it must be
+    (almost) never, otherwise the physics would deviate from nconmax=100 njmax=500 (hsr/models/world.xml:44)."""
+    import sys
+    from pathlib import Path
+    sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+    from bench import sample_inputs
+    m = models["cfg3"]
+    n = 8192
+    q0, goal = sample_inputs(m, n, 0, 0)
+    sim = hs.BatchSim(m, n)
+    sim.reset(qpos0=q0, mocap=goal)
+    sim.cap_counts()
+    rng = np.random.default_rng(1)
+    for k in range(2):
+        ctrl = rng.uniform(m.act_ctrlrange[:, 0], m.act_ctrlrange[:, 1], (n, m.nu)).astype(np.float32)
+        sim.step(ctrl, 300, m.body_id("block0"), 0.05)
+    c_con, c_row, c_item, total = sim.cap_counts()
+    print(f"cap hits over {total} env-substeps: contacts {c_con}, rows {c_row}, items {c_item}")
+    assert total >= 2 * 300 * n * 0.99
+    assert c_item == 0 and c_con <= 1e-5 * total and c_row <= 1e-5 * total
+    sim.close()

@@ -101,8 +101,9 @@ def test_forward_stages_match_oracle(models, cfg):
 
 @pytest.mark.parametrize("cfg", ["cfg1", "cfg2", "cfg3", "cfg4", "cupboard"])
 def test_single_substep_matches_oracle(models, cfg):
-    """One substep from identical states: |dqpos| < 5e-6, |dqvel| < 1e-4 (1 + |qvel|) for >= 98 % of
-    envs (a contact that exists in only one precision may flip an env)."""
+    """One substep from identical states through the persistent kernel: |dqpos| < 5e-6, |dqvel| < 1e-4 (1 + |qvel|).  An env
+    outside the tolerance must be EXPLAINED by a contact that exists in only one precision (HIP contact count of that substep
+    != the oracle's; at most 2 % of the envs): an unexplained env fails the test.  The counts are printed."""
     m = models[cfg]
     n = 128
     rng = np.random.default_rng(11)
@@ -110,19 +111,23 @@ def test_single_substep_matches_oracle(models, cfg):
     pre = oracle_rollout(m, q, v, ctrl, 60)
     q = np.array([s.qpos for s in pre]); v = np.array([s.qvel for s in pre]); w = np.array([s.qacc_warmstart for s in pre])
     sim = hs.BatchSim(m, n)
+    sim.set_debug(True)
     sim.set_warmstart(w)
     sim.set_state(np.zeros(n), q, v)
     obs, rew, done, ns = sim.step(ctrl, 1)
+    ncon = sim.get_field(hs.F_NCON)
     assert (ns == 1).all() and not done.any()
-    bad = 0
+    explained, unexplained = [], []
     for e in range(n):
         o = pre[e]
         o.step()
         dq = np.abs(obs[e, :m.nq] - o.qpos).max()
         dv = (np.abs(obs[e, m.nq:] - o.qvel) / (1 + np.abs(o.qvel))).max()
         if not (dq < 5e-6 and dv < 1e-4):
-            bad += 1
-    assert bad <= max(1, n // 50), f"{bad}/{n} envs outside tolerance"
+            (explained if int(ncon[e]) != o.ncon else unexplained).append((e, float(dq), float(dv), int(ncon[e]), o.ncon))
+    print(f"{cfg}: {len(explained)} envs outside tolerance with a different contact count, {len(unexplained)} unexplained")
+    assert not unexplained, unexplained[:5]
+    assert len(explained) <= max(1, n // 50), explained[:5]
     assert not sim.bad_state()[1]
     sim.close()
 
@@ -207,25 +212,25 @@ def test_masked_reset_and_body_xpos(models):
     sim.close()
 
 
-def test_determinism_and_graph_equivalence(models):
-    """Same inputs -> bit-identical outputs across runs and between hipGraph replay and plain launches."""
+def test_determinism(models):
+    """Same inputs -> bit-identical outputs across runs of the persistent kernel (hipGraph replay of the per-substep chain is
+    compared with plain launches in test_gpu_hotpath.py)."""
     m = models["cfg3"]
     n = 128
     rng = np.random.default_rng(15)
     q, v, ctrl = random_states(m, n, rng)
     outs = []
-    for use_graph in (True, False, True):
+    for rep in range(3):
         sim = hs.BatchSim(m, n)
-        sim.set_graph(use_graph)
+        assert sim.is_persistent()
         sim.set_state(np.zeros(n), q, v)
         o1 = sim.step(ctrl, 50)[0]
         o2 = sim.step(ctrl, 50)[0]
         outs.append((o1.copy(), o2.copy()))
         sim.close()
-    for a, b in zip(outs[0], outs[1]):
-        assert np.array_equal(a, b)
-    for a, b in zip(outs[0], outs[2]):
-        assert np.array_equal(a, b)
+    for k in (1, 2):
+        for a, b in zip(outs[0], outs[k]):
+            assert np.array_equal(a, b)
 
 
 def test_full_size_invariants(models):
