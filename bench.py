@@ -90,7 +90,8 @@ def cpu_baseline(m, q0, goal, ctrl, cores):
     n = int(min(N, max(n_cal, budget / max(per_env_step, 1e-9))))
     reps = int(max(1, min(8, budget / max(per_env_step * n, 1e-9))))
     dt = run(n, reps)
-    n1 = int(max(1, min(n, 5.0 / max(per_env_step * cores, 1e-9))))     # about 5 s on one thread
+    t1 = run(min(N, 16), 1, threads=1) / min(N, 16)                       # calibrate one thread, then about 5 s on it
+    n1 = int(max(1, min(N, 5.0 / max(t1, 1e-9))))
     dt1 = run(n1, 1, threads=1)
     return dict(value=n * reps / dt, unit="env-steps/s", cores=cores, kind="port",
                 single_core={"value": n1 / dt1, "unit": "env-steps/s", "cores": 1, "sample": f"first {n1} envs x 1 env-step ({dt1:.1f} s)"},
@@ -133,9 +134,14 @@ def main():
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="control-flow rehearsal of the N>1 path on a box with one GPU: every rank uses cuda:0 and the all-gather "
                          "goes through gloo on host copies (RCCL refuses two ranks on one device); the number it prints is not a result")
+    ap.add_argument("--launch-check", action="store_true", help="print this rank's rendezvous environment and exit (no GPU touched): "
+                    "exercises the self-launcher of --gpus N on a machine without GPUs")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(args))
+    if args.launch_check:
+        print(json.dumps({k: os.environ.get(k) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}))
+        return
 
     import torch
     from hsr_env_amd.compiler import load_config

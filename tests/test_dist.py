@@ -64,3 +64,22 @@ def test_shard_range_partitions():
             r = [shard_range(n, k, w) for k in range(w)]
             assert r[0][0] == 0 and r[-1][1] == n and all(a[1] == b[0] for a, b in zip(r, r[1:]))
             assert max(h - l for l, h in r) - min(h - l for l, h in r) <= 1
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus N` as a plain command (no torch.distributed.run): the parent starts N ranks with an env://
+    rendezvous on 127.0.0.1, relays rank 0's line and returns the worst exit code - checked here without a GPU."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "3", "--launch-check"], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["RANK"] == "0" and line["WORLD_SIZE"] == "3" and line["MASTER_ADDR"] == "127.0.0.1" and int(line["MASTER_PORT"]) > 0
+    # a failing rank fails the launch: without a GPU every rank exits non-zero
+    r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
