@@ -673,13 +673,20 @@ __global__ void k_mask_from_done(DevState s, uint8_t *mask) {
     int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e < s.N) mask[e] = (uint8_t)(s.done[e] != 0);
 }
+// the forward pass after a masked reset concerns the reset envs only (the reference's reset() touches one env): the others are
+// parked as "done" for that pass, so its kernels skip them (whole waves return when none of their envs was reset)
+__global__ void k_park_unmasked(DevState s, const uint8_t *mask) {
+    int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < s.N) s.done[e] = mask[e] ? 0 : 1;
+}
 extern "C" int hsr_batch_reset_dev(hsr_batch *b, const uint8_t *d_mask, const float *d_qpos0, const float *d_mocap) {
     HIPCHK(hipSetDevice(b->device));
     const size_t N = b->N;
     if (!d_mask) { hipLaunchKernelGGL(k_mask_from_done, grid1(N), dim3(256), 0, b->stream, b->ds, b->d_stage_u8); d_mask = b->d_stage_u8; }
     hipLaunchKernelGGL(k_reset, grid1(N), dim3(256), 0, b->stream, b->dm, b->ds, d_mask, d_qpos0, (const float *)b->d_qpos0, d_mocap);
-    hipLaunchKernelGGL(k_clear_done, grid1(N), dim3(256), 0, b->stream, b->ds);
+    hipLaunchKernelGGL(k_park_unmasked, grid1(N), dim3(256), 0, b->stream, b->ds, d_mask);
     launch_substep(b, 0, -1, 0.f, 0, b->stream, false);
+    hipLaunchKernelGGL(k_clear_done, grid1(N), dim3(256), 0, b->stream, b->ds);
     HIPCHK(hipGetLastError());
     return HSR_OK;
 }

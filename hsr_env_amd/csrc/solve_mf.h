@@ -20,7 +20,7 @@ enum { C2_POS = 0, C2_L1 = 3, C2_N = 4, C2_L2 = 7, C2_T1 = 8, C2_ADR = 11, C2_T2
 __device__ __forceinline__ float4 lds4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 
 template <int G> struct MfLayout {
-    int R, MS, oRows, oB, oLv, total;
+    int R, MS, oRows, oB, oLv, total, envf;
     __host__ __device__ MfLayout(int rows, int kstride) {
         R = rows; MS = G + 1;
         const int a = 5 * R > kstride ? 5 * R : kstride;                    // row scalars; the kin record aliases them early on
@@ -28,6 +28,7 @@ template <int G> struct MfLayout {
         oRows = 0; oB = (a + 3) & ~3;
         oLv = (oB + b + 3) & ~3;                                            // per-link velocity fields of jmul: 5 links x 6
         total = oLv + 32;
+        envf = total;                                                       // LDS floats per env (the name the shared solver body uses)
     }
 };
 
