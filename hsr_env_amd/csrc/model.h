@@ -57,6 +57,9 @@ struct DevState {
     // dynamics / solver outputs kept for introspection
     float *M, *qacc, *qacc_smooth, *qfrc_smooth, *qfrc_constraint;
     int *ncon, *nefc, *niter;
+    // wave packing of the persistent kernel: slot_env[workgroup * envs_per_workgroup + group] = env index or -1 (NULL: identity);
+    // trips[e] = Newton iterations env e ran in the last substeps of its last launch (what the packing is derived from)
+    int *slot_env, *trips;
     unsigned long long *capstat;     // [4] cap statistics (include/hsrsim.h: hsr_batch_cap_counts)
     unsigned long long *phase_cyc;   // diagnostic build only (HSR_PHASE_TIMING): per-phase cycle sums
 };

@@ -55,13 +55,14 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
     const int mode = 1, debug = 0;
     const bool dbg_store = flags & 1;          // introspection: contact counts / solver counters of each env's last substep go to global memory
     int cap_con = 0, cap_row = 0, cap_item = 0, nsub_run = 0;      // cap statistics of this lane's env (lane c == 0 reports)
+    int own_trips = 0;                                              // Newton iterations of this lane's env over its last (up to) 100 substeps
     // everything derived from the lane id is declared through this macro: once for the prologue, once per substep from a
     // laundered copy of the lane id (so that LLVM does not hoist ~100 loop-invariant addresses out of the substep loop and
     // then spill them), once for the epilogue
 #define PERSIST_LANE_VIEW(TID)                                                                                              \
     const int tid = (TID), g = tid / G, c = tid % G;                                                                         \
-    const int e_raw = blockIdx.x * EPB + g;                                                                                  \
-    const bool in_range = e_raw < N;                                                                                         \
+    const int e_raw = s.slot_env ? s.slot_env[blockIdx.x * EPB + g] : blockIdx.x * EPB + g;                                  \
+    const bool in_range = e_raw >= 0 && e_raw < N;                                                                           \
     const int e = in_range ? e_raw : 0;                                                                                      \
     float *E = lds + (size_t)g * L.envf;                                                                                     \
     float *rD = E + L.oRows, *rAref = rD + R, *rJar = rAref + R, *rJv = rJar + R, *rDw = rJv + R;            \
@@ -86,6 +87,8 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
     if (tid0 < nv) sParent[tid0] = m.dof_parent[tid0];
     if (tid0 < m.nlink && tid0 < NLMAX) { sMask[tid0] = m.link_dofmask[tid0]; sMass[tid0] = m.link_mass[tid0]; }
     __shared__ unsigned char sDofLink[32];
+    __shared__ int sEnv[64 / G];                       // env index of every lane group of this workgroup (wave packing: DevState::slot_env)
+    if (tid0 % G == 0) { const int er = s.slot_env ? s.slot_env[blockIdx.x * EPB + tid0 / G] : blockIdx.x * EPB + tid0 / G; sEnv[tid0 / G] = (er >= 0 && er < N) ? er : 0; }
     if (tid0 < nv) sDofLink[tid0] = (unsigned char)m.dof_link[tid0];
     if (tid0 < m.nlink) kin2_store(m, tid0, lds + L.oKin + KIN2_FLOATS * tid0);
     // geom cache: constants of every geom, placements of the static ones (world link: identity pose)
@@ -330,7 +333,7 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
                     float rb;
                     A = geom_cached3(gaddr(pk_g1(pk), Ei), gcc + 8 * pk_g1(pk), m.mesh_vert4, rb);
                     B = geom_cached3(gaddr(pk_g2(pk), Ei), gcc + 8 * pk_g2(pk), m.mesh_vert4, rb);
-                    o.con = s.con + (size_t)(blockIdx.x * EPB + ig) * m.nslot * 8; o.slot = (int)pb.y; o.maxcnt = (int)pb.z; o.cnt = 0;
+                    o.con = s.con + (size_t)sEnv[ig] * m.nslot * 8; o.slot = (int)pb.y; o.maxcnt = (int)pb.z; o.cnt = 0;
                     cntp = reinterpret_cast<unsigned char *>(Ei + L.oCnt) + p;
                 };
                 PHASE(20);
@@ -359,7 +362,7 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
                             // separation is left after the geoms' moves since (upper bounds, geom cache slot 15): while it is
                             // positive the pair is still separated along d and nothing is scanned; otherwise both hulls are scanned
                             // along d and the margin is refreshed; MPR runs only when d no longer separates
-                            float *sx = s.sepax + (size_t)(4 * (it2 & 0x3fff)) * N + (blockIdx.x * EPB + (it2 >> 14));
+                            float *sx = s.sepax + (size_t)(4 * (it2 & 0x3fff)) * N + sEnv[it2 >> 14];
                             const v3 d = mk3(sx[0], sx[N], sx[2 * (size_t)N]);
                             float mg = sx[3 * (size_t)N];
                             {
@@ -467,6 +470,7 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
                 if (reach) done = true;          // a-4: latch; the env skips the remaining substeps
             }
             trips_acc += newton_trips;
+            if (valid && n_substeps - sub <= 100) own_trips += iter;
             wave_sync();
             PHASE(18);
         }
@@ -482,6 +486,7 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
             if (cap_row) atomicAdd(&s.capstat[1], (unsigned long long)cap_row);
             if (cap_item) atomicAdd(&s.capstat[2], (unsigned long long)cap_item);
             atomicAdd(&s.capstat[3], (unsigned long long)nsub_run);
+            s.trips[e] = own_trips;
             s.time[e] = time_e; s.nsteps[e] = s.nsteps[e] + nsteps_e;
             if (bsum > 0) s.bad[e] = 1;
             if (done) s.done[e] = 1;

@@ -111,13 +111,6 @@ template <int G> __device__ __forceinline__ int gmax(int v) {    // maximum over
     if constexpr (G == 16) return v;
     else { const auto sw = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false); const int a = (int)sw[0], b = (int)sw[1]; return a > b ? a : b; }
 }
-// sum over the four 16-lane rows of the wave, in every lane (gfx950 v_permlane16_swap / v_permlane32_swap of a value with itself)
-__device__ __forceinline__ float wave_rowsum4(float v) {
-    const auto s1 = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
-    v = __builtin_bit_cast(float, (unsigned)s1[0]) + __builtin_bit_cast(float, (unsigned)s1[1]);
-    const auto s2 = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
-    return __builtin_bit_cast(float, (unsigned)s2[0]) + __builtin_bit_cast(float, (unsigned)s2[1]);
-}
 // OR / maximum of a group-uniform value over the env groups of the wave, as a scalar (v_readlane ignores EXEC: call it from
 // wave-uniform control flow only, with the value defined in every lane)
 template <int G> __device__ __forceinline__ int wave_or_groups(int v) {

@@ -223,3 +223,41 @@ def test_cap_counters_and_full_size(models):
     assert total >= 2 * 300 * n * 0.99
     assert c_item == 0 and c_con <= 1e-5 * total and c_row <= 1e-5 * total
     sim.close()
+
+
+@pytest.mark.parametrize("cfg", ["cfg3", "cfg4"])
+def test_wave_packing_never_changes_a_result(models, cfg):
+    """The persistent kernel can re-pack the envs over its waves before every launch (hard envs one per wave, easiest envs as
+    neighbours).  That is a scheduling decision: with the packing on or off, and with the batch permuted, every env must give
+    bit-identical results over several env-steps - no value of an env may ever depend on its wave neighbours (the contact-rich
+    random states make sure that envs with many Newton iterations are among them)."""
+    m = models[cfg]
+    n = 512
+    rng = np.random.default_rng(77)
+    q, v, ctrl = random_states(m, n, rng)
+    goal = np.column_stack([rng.uniform(-0.1, 0.1, n), rng.uniform(-0.2, 0.2, n), np.full(n, 0.422)])
+    bid = m.body_id(m.block_body())
+    ctrls = [rng.uniform(m.act_ctrlrange[:, 0], m.act_ctrlrange[:, 1], (n, m.nu)).astype(np.float32) for _ in range(3)]
+    perm = rng.permutation(n)
+
+    def run(schedule, order):
+        sim = hs.BatchSim(m, n)
+        sim.set_schedule(schedule)
+        sim.reset(qpos0=q[order], mocap=goal[order])
+        outs = []
+        for c in ctrls:
+            obs, rew, done, ns = sim.step(c[order], 100, bid, 0.03)
+            outs.append((obs.copy(), done.copy(), ns.copy()))
+        sim.close()
+        return outs
+
+    ident = np.arange(n)
+    ref = run(False, ident)
+    on = run(True, ident)
+    shuffled = run(True, perm)
+    inv = np.argsort(perm)
+    for k in range(len(ctrls)):
+        for a, b in zip(ref[k], on[k]):
+            assert np.array_equal(a, b), f"packing changed a result in env-step {k}"
+        for a, b in zip(ref[k], shuffled[k]):
+            assert np.array_equal(a, b[inv]), f"the position in the batch changed a result in env-step {k}"
