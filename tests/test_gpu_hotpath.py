@@ -261,3 +261,44 @@ def test_wave_packing_never_changes_a_result(models, cfg):
             assert np.array_equal(a, b), f"packing changed a result in env-step {k}"
         for a, b in zip(ref[k], shuffled[k]):
             assert np.array_equal(a, b[inv]), f"the position in the batch changed a result in env-step {k}"
+
+
+def test_rl_plumbing_on_the_device(models):
+    """SURVEY 8f row 4 on hardware: transitions produced by BatchSim.step_dev go into the DeviceReplayBuffer without visiting the
+    host (torch tensors on cuda:0, ordered after the step through the batch's stream), and TimeLimit truncates the vectorised env."""
+    import torch
+    from hsr_env_amd import GoalSpec, VecHSREnv
+    from hsr_env_amd.rl import DeviceReplayBuffer, TimeLimit
+    m = models["cfg3"]
+    n = 64
+    dev = torch.device("cuda", 0)
+    sim = hs.BatchSim(m, n)
+    rng = np.random.default_rng(5)
+    q, v, ctrl = random_states(m, n, rng)
+    sim.set_state(np.zeros(n), q, v)
+    buf = DeviceReplayBuffer(4 * n, device=dev)
+    d_obs = torch.empty((n, m.nq + m.nv), dtype=torch.float32, device=dev); d_rew = torch.empty(n, dtype=torch.float32, device=dev)
+    d_done = torch.empty(n, dtype=torch.uint8, device=dev); d_ns = torch.empty(n, dtype=torch.int32, device=dev)
+    ext = torch.cuda.ExternalStream(sim.stream_ptr(), device=dev)
+    host = []
+    with torch.cuda.stream(ext):
+        for k in range(6):
+            d_ctrl = torch.from_numpy(ctrl.astype(np.float32)).to(dev)
+            sim.step_dev(d_ctrl.data_ptr(), 10, -1, 0.0, d_obs.data_ptr(), d_rew.data_ptr(), d_done.data_ptr(), d_ns.data_ptr())
+            buf.extend((d_obs.clone(), d_rew.clone(), d_done.clone()))
+            host.append(d_obs.cpu().numpy().copy())
+    torch.cuda.synchronize()
+    assert len(buf) == 4 * n and buf.full and buf.buffer[0].device.type == "cuda"
+    newest = buf[-n:0][0].cpu().numpy()
+    oldest = buf[-4 * n:-3 * n][0].cpu().numpy()
+    assert np.array_equal(newest, host[-1]) and np.array_equal(oldest, host[2])
+    o, r, d = buf.sample(32)
+    assert o.shape == (32, m.nq + m.nv) and o.device.type == "cuda"
+    sim.close()
+    env = TimeLimit(VecHSREnv(model=models["cfg2"], n_envs=4, goals=[GoalSpec("block0", np.array([.4, 0, .422]), .05)], steps_per_action=3), 2)
+    env.reset()
+    _, _, done, info = env.step(np.zeros((4, 2)))
+    assert not done.any()
+    _, _, done, info = env.step(np.zeros((4, 2)))
+    assert done.all() and info["TimeLimit.truncated"].all()
+    env.close()
