@@ -622,6 +622,18 @@ extern "C" int hsr_batch_set_persistent(hsr_batch *b, int on) {
 extern "C" int hsr_batch_is_persistent(const hsr_batch *b) { return b->persist ? 1 : 0; }
 extern "C" int hsr_batch_set_debug(hsr_batch *b, int on) { b->debug_store = on != 0; return HSR_OK; }
 extern "C" int hsr_batch_set_schedule(hsr_batch *b, int on) { b->schedule = on != 0; return HSR_OK; }
+extern "C" int hsr_batch_set_goals(hsr_batch *b, int n, const int *body_a, const int *body_b, const float *dist) {
+    if (!b || n < 0 || n > 4 || (n > 0 && (!body_a || !body_b || !dist))) return fail(HSR_EINVAL, "hsr_batch_set_goals: 0..4 terms");
+    for (int k = 0; k < n; k++)
+        if (body_a[k] < 0 || body_a[k] >= b->dm.nbody || body_b[k] < 0 || body_b[k] >= b->dm.nbody) return fail(HSR_EINVAL, "hsr_batch_set_goals: body id out of range");
+    HIPCHK(hipSetDevice(b->device));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    b->ds.ngoal = n;
+    for (int k = 0; k < n; k++) { b->ds.goal_a[k] = body_a[k]; b->ds.goal_b[k] = body_b[k]; b->ds.goal_d[k] = dist[k]; }
+    for (auto &kv : b->graphs) hipGraphExecDestroy(kv.second);      // captured launches carry the old terms
+    b->graphs.clear();
+    return HSR_OK;
+}
 extern "C" int hsr_batch_cap_counts(hsr_batch *b, unsigned long long *out) {
     if (!b || !out) return fail(HSR_EINVAL, "null argument");
     HIPCHK(hipSetDevice(b->device));

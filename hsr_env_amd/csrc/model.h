@@ -57,6 +57,10 @@ struct DevState {
     // dynamics / solver outputs kept for introspection
     float *M, *qacc, *qacc_smooth, *qfrc_smooth, *qfrc_constraint;
     int *ncon, *nefc, *niter;
+    // further goal terms AND-ed with the main one (hsr/env.py:124-126 `all(in_range(*g) for g in goals)`): term k holds when
+    // |point(goal_a[k]) - point(goal_b[k])| < goal_d[k], point(body) = its xpos, or the env's mocap point for a mocap body
+    int ngoal, goal_a[4], goal_b[4];
+    float goal_d[4];
     // wave packing of the persistent kernel: slot_env[workgroup * envs_per_workgroup + group] = env index or -1 (NULL: identity);
     // trips[e] = Newton iterations env e ran in the last substeps of its last launch (what the packing is derived from)
     int *slot_env, *trips;

@@ -193,10 +193,23 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
         if (!(fabsf(qpos_c) <= 1e10f) || !(fabsf(qvel_c) <= 1e10f)) bad = 1;
         // a-3 goal test uses the xpos of this substep's forward pass
         bool reach = false;
-        if (goal_body >= 0) {
-            v3 bp = goal;
-            if (goal_link >= 0) { m3 Rg; v3 pg; pose_load(poseL + 12 * goal_link, Rg, pg); bp = pg + mulmv(Rg, goal_off); }
-            reach = norm(bp - goal) < geofence;
+        if (goal_body >= 0 || s.ngoal > 0) {
+            reach = true;
+            if (goal_body >= 0) {
+                v3 bp = goal;
+                if (goal_link >= 0) { m3 Rg; v3 pg; pose_load(poseL + 12 * goal_link, Rg, pg); bp = pg + mulmv(Rg, goal_off); }
+                reach = norm(bp - goal) < geofence;
+            }
+            for (int k = 0; k < s.ngoal; k++) {
+                v3 pt[2];
+#pragma unroll
+                for (int w = 0; w < 2; w++) {
+                    const int body = w == 0 ? s.goal_a[k] : s.goal_b[k];
+                    pt[w] = goal;
+                    if (!m.body_mocap[body]) { m3 Rg; v3 pg; pose_load(poseL + 12 * m.body_link[body], Rg, pg); pt[w] = pg + mulmv(Rg, ld3(m.body_pos, body)); }
+                }
+                reach = reach && norm(pt[0] - pt[1]) < s.goal_d[k];
+            }
         }
         // link poses of an env's last substep go to global memory (sim.data.get_body_xpos after step(), hsr/env.py:144)
         if (valid && (sub == n_substeps - 1 || reach)) {

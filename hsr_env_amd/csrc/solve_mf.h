@@ -127,15 +127,17 @@ __global__ void __launch_bounds__(64, 2) k_solve_mf(DevModel m, DevState s, int 
     int nsteps0 = 0;
     if (valid && c == 0) {
         time0 = s.time[e]; nsteps0 = s.nsteps[e];
-        if (goal_body >= 0 && mode != 0) {
+        if ((goal_body >= 0 || s.ngoal > 0) && mode != 0) {
             const v3 goal = mk3(s.mocap[e], s.mocap[N + e], s.mocap[2 * N + e]);
-            v3 bp = goal;
-            if (!m.body_mocap[goal_body]) {
-                const int l = m.body_link[goal_body];
-                View xpos{s.xpos + e, N}, xmat{s.xmat + e, N};
-                bp = xpos.get3(l) + mulmv(xmat.getm(l), ld3(m.body_pos, goal_body));
-            }
-            reach = norm(bp - goal) < geofence;
+            View xpos{s.xpos + e, N}, xmat{s.xmat + e, N};
+            auto body_point = [&](int body) -> v3 {
+                if (m.body_mocap[body]) return goal;
+                const int l = m.body_link[body];
+                return xpos.get3(l) + mulmv(xmat.getm(l), ld3(m.body_pos, body));
+            };
+            reach = true;
+            if (goal_body >= 0) reach = norm(body_point(goal_body) - goal) < geofence;
+            for (int k = 0; k < s.ngoal; k++) reach = reach && norm(body_point(s.goal_a[k]) - body_point(s.goal_b[k])) < s.goal_d[k];
         }
     }
 #define SOLVE_STORE_DIAG true

@@ -98,15 +98,37 @@ class VecHSREnv:
         return x[0] if self.n_envs == 1 else x
 
     def _parse_goals(self):
+        """hsr/env.py:124-126,137-147: `done = all(in_range(a, b, d) for a, b, d in goals)`, an operand being a body name
+        (its xpos), a point (ndarray, or a Space sampled at reset) or a callable.  On the device a goal is a pair of bodies, or a
+        body and THE point: like the reference, whose reset writes the concatenation of all point operands into the single
+        mocap_pos[1, 3] (hsr/env.py:169-172), at most one point operand can exist across the goals.  The goal that holds the
+        point is the main term of hsr_batch_step (goal_body, geofence); body-body goals become the extra terms of
+        hsr_batch_set_goals (the mocap body stands for the point there).  Callables cannot run inside the substep loop."""
+        self._goal_body, self._geofence, self._point_goal, self._extra_terms = -1, 0.0, None, []
         if not self.goals_specs:
             return
-        if len(self.goals_specs) != 1:
-            raise NotImplementedError("the device goal test supports one GoalSpec (the reference CLI builds exactly one, hsr/util.py:70-74)")
-        a, b, d = self.goals_specs[0]
-        if not isinstance(a, str):
-            raise RuntimeError(f"{a} must be function, np.ndarray, or string")   # hsr/env.py:145 (only names run on device)
-        self._goal_body = self.model.body_id(a)
-        self._geofence = float(d)
+        mocap_body = next((i for i, mc in enumerate(self.model.arrays["body_mocap"]) if mc), None)
+        for gi, (a, b, d) in enumerate(self.goals_specs):
+            for x in (a, b):
+                if callable(x) and not isinstance(x, Space):
+                    raise RuntimeError(f"{x} must be np.ndarray or string: callables cannot be evaluated inside the device substep loop")
+                if not isinstance(x, (str, np.ndarray, Space, list, tuple)):
+                    raise RuntimeError(f"{x} must be function, np.ndarray, or string")      # hsr/env.py:145
+            points = [x for x in (a, b) if not isinstance(x, str)]
+            if len(points) == 2:
+                raise RuntimeError("a goal between two points does not depend on the simulation")
+            if points:
+                if self._point_goal is not None:
+                    raise ValueError("the goals hold more than one point operand: mocap_pos has room for one (hsr/env.py:169-172)")
+                body = a if isinstance(a, str) else b
+                self._point_goal, self._goal_body, self._geofence = gi, self.model.body_id(body), float(d)
+            else:
+                self._extra_terms.append((self.model.body_id(a), self.model.body_id(b), float(d)))
+        if len(self._extra_terms) > 4:
+            raise NotImplementedError("at most four body-body goals besides the point goal")
+        if self._extra_terms and not hasattr(self.sim, "set_goals"):
+            raise NotImplementedError("this simulator handle does not evaluate body-body goals")
+        del mocap_body
 
     @property
     def dt(self):
@@ -150,11 +172,17 @@ class VecHSREnv:
         m = np.ones(self.n_envs, dtype=bool) if mask is None else np.asarray(mask, dtype=bool).reshape(self.n_envs)
         self._time_steps[m] = 0
         if self.goals_specs:
-            a, b, d = self.goals_specs[0]
-            pts = b.sample(self.n_global, rng=rng) if isinstance(b, Space) else np.tile(np.asarray(b, dtype=np.float32), (self.n_global, 1))
-            pts = self._shard(np.asarray(pts, dtype=np.float32).reshape(self.n_global, 3))
-            self._goal_points[m] = pts[m]
-            self.goals = [GoalSpec(a, self._squeeze(self._goal_points), d)]
+            if self._extra_terms and self.goals is None:
+                self.sim.set_goals(self._extra_terms)               # from the first reset on (before it `goals is None`: hsr/env.py:39,125)
+            self.goals = list(self.goals_specs)
+            if self._point_goal is not None:
+                a, b, d = self.goals_specs[self._point_goal]
+                pt = b if isinstance(a, str) else a
+                pts = pt.sample(self.n_global, rng=rng) if isinstance(pt, Space) else np.tile(np.asarray(pt, dtype=np.float32), (self.n_global, 1))
+                pts = self._shard(np.asarray(pts, dtype=np.float32).reshape(self.n_global, 3))
+                self._goal_points[m] = pts[m]
+                cur = self._squeeze(self._goal_points)
+                self.goals[self._point_goal] = GoalSpec(a, cur, d) if isinstance(a, str) else GoalSpec(cur, b, d)
         qpos = self.new_state(rng).astype(np.float32)
         self.sim.reset(mask=m.astype(np.uint8), qpos0=qpos, mocap=self._goal_points)
         return self._get_observation()
@@ -182,6 +210,7 @@ class VecHSREnv:
         action = np.asarray(action, dtype=np.float32).reshape(self.n_envs, self.model.nu)
         steps = steps or self.steps_per_action
         goal_body = self._goal_body if self.goals else -1
+
         obs, rew, done, ns = self.sim.step(action, steps, goal_body, self._geofence)
         bad_state = getattr(self.sim, "bad_state", None)
         if bad_state is not None:

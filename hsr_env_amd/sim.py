@@ -36,7 +36,7 @@ EXPORTS = [
     "hsr_batch_set_warmstart", "hsr_batch_get_warmstart", "hsr_batch_forward", "hsr_batch_step",
     "hsr_batch_step_dev", "hsr_batch_body_xpos", "hsr_batch_bad_state", "hsr_batch_get_field",
     "hsr_batch_set_profiling", "hsr_batch_last_timing", "hsr_batch_set_graph", "hsr_batch_set_persistent", "hsr_batch_is_persistent",
-    "hsr_batch_obs_openai", "hsr_batch_obs_openai_dev", "hsr_batch_set_debug", "hsr_batch_cap_counts", "hsr_batch_set_schedule",
+    "hsr_batch_obs_openai", "hsr_batch_obs_openai_dev", "hsr_batch_set_debug", "hsr_batch_cap_counts", "hsr_batch_set_schedule", "hsr_batch_set_goals",
     "hsr_batch_phase_cycles", "hsr_batch_block_times",
 ]
 
@@ -92,6 +92,7 @@ def load_library():
     L.hsr_batch_is_persistent.argtypes = [vp]
     L.hsr_batch_set_debug.argtypes = [vp, C.c_int]
     L.hsr_batch_set_schedule.argtypes = [vp, C.c_int]
+    L.hsr_batch_set_goals.argtypes = [vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), fp]
     L.hsr_batch_cap_counts.argtypes = [vp, C.POINTER(C.c_ulonglong)]
     _lib = L
     return L
@@ -258,6 +259,13 @@ class BatchSim:
     def set_debug(self, on: bool):
         """Also store the contact counts / solver counters of each env's last substep during step() (persistent kernel)."""
         _check(self._L, self._L.hsr_batch_set_debug(self._b, int(on)))
+
+    def set_goals(self, terms):
+        """Further goal terms [(body_a, body_b, distance), ...] AND-ed with the main term of step() (include/hsrsim.h)."""
+        n = len(terms)
+        a = (C.c_int * max(n, 1))(*[int(t[0]) for t in terms]); b = (C.c_int * max(n, 1))(*[int(t[1]) for t in terms])
+        d = (C.c_float * max(n, 1))(*[float(t[2]) for t in terms])
+        _check(self._L, self._L.hsr_batch_set_goals(self._b, n, a, b, d))
 
     def set_schedule(self, on: bool):
         """Wave packing of the persistent kernel by env hardness (default off); never changes a result."""

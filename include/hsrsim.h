@@ -82,6 +82,11 @@ int hsr_batch_step(hsr_batch *b, const float *ctrl /*[N,nu]*/, int n_substeps, i
 int hsr_batch_step_dev(hsr_batch *b, const float *d_ctrl, int n_substeps, int goal_body, float geofence,
                        float *d_obs, float *d_reward, uint8_t *d_done, int32_t *d_nsteps);
 
+/* Further goal terms, AND-ed per substep with the main term of hsr_batch_step* - `all(in_range(*g) for g in goals)`,
+ * hsr/env.py:124-126,137-147: term k holds when |p(body_a[k]) - p(body_b[k])| < dist[k], p(body) = its xpos, or the env's mocap
+ * point when the body is the mocap body.  n = 0..4 (0 clears); with goal_body < 0 in hsr_batch_step* the terms alone decide. */
+int hsr_batch_set_goals(hsr_batch *b, int n, const int *body_a, const int *body_b, const float *dist);
+
 /* sim.data.get_body_xpos(name) for every env (hsr/env.py:144,180,184); valid after forward/step */
 int hsr_batch_body_xpos(hsr_batch *b, int body_id, float *out /*[N,3]*/);
 

@@ -302,3 +302,38 @@ def test_rl_plumbing_on_the_device(models):
     _, _, done, info = env.step(np.zeros((4, 2)))
     assert done.all() and info["TimeLimit.truncated"].all()
     env.close()
+
+
+def test_several_goals_all_in_range(models):
+    """hsr/env.py:124-126: done = all(in_range(*g) for g in goals), tested after every substep.  Two goals - the block within a
+    geofence of the sampled point (written to mocap_pos) AND a finger within reach of the block - against the oracle stepped
+    substep by substep with the same test in Python; persistent kernel and per-substep chain."""
+    from hsr_env_amd import GoalSpec, VecHSREnv
+    m = models["cfg3"]
+    n = 48
+    rng = np.random.default_rng(9)
+    q, v, ctrl = random_states(m, n, rng)
+    point = q[:, 7:10].copy(); point[n // 2:, 0] += 0.25                 # half of the points at the block, half away
+    d_point, d_body = 0.04, 0.75
+    bid, fid = m.body_id("block0"), m.body_id("hand_l_distal_link")
+    for persistent in (True, False):
+        sim = hs.BatchSim(m, n)
+        sim.set_persistent(persistent)
+        env = VecHSREnv(model=m, n_envs=n, sim=sim, steps_per_action=60,
+                        goals=[GoalSpec("block0", np.zeros(3), d_point), GoalSpec("hand_l_distal_link", "block0", d_body)])
+        env.reset()
+        env._goal_points[:] = point                                      # per-env points (a Box would be sampled; fixed here)
+        sim.reset(qpos0=q.astype(np.float32), mocap=point.astype(np.float32))
+        obs, rew, done, info = env.step(ctrl)
+        ns = info["substeps"]
+        for e in range(n):
+            o = OracleSim(m)
+            o.qpos[:] = q[e]; o.mocap_pos[:] = point[e]; o.ctrl[:] = ctrl[e]
+            k, dn = 0, False
+            while k < 60 and not dn:
+                o.step(); k += 1
+                pb, pf = o.body_xpos(bid), o.body_xpos(fid)
+                dn = np.linalg.norm(pb - point[e]) < d_point and np.linalg.norm(pf - pb) < d_body
+            assert dn == bool(done[e]) and abs(k - int(ns[e])) <= (1 if dn else 0), (persistent, e, k, int(ns[e]), dn, bool(done[e]))
+        assert done.any() and not done.all()
+        env.close()
