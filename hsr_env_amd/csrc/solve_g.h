@@ -11,6 +11,12 @@
 #ifndef HSR_LAST_DEC
 #define HSR_LAST_DEC 1e-6f      // 100 x the solver tolerance of 1e-8 (solve_body.inc, Newton loop)
 #endif
+#ifndef HSR_LS_FAR
+#define HSR_LS_FAR 1e-4f        // scaled Newton decrement above which the line search stops at HSR_LS_REL_FAR instead of HSR_LS_REL
+#endif
+#ifndef HSR_LS_REL_FAR
+#define HSR_LS_REL_FAR 0.05f
+#endif
 #ifndef HSR_LS_REL
 #define HSR_LS_REL 1e-3f        // relative stop of the exact line search: |phi'(alpha)| < HSR_LS_REL |phi'(0)|
 #endif
