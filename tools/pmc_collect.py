@@ -1,0 +1,44 @@
+"""Condense the rocprofv3 outputs of tools/profile_round.sh into profiles/: the kernel-trace stats CSV of the bench command and
+pmc_summary.json (HBM-side bytes per launch from FETCH_SIZE / WRITE_SIZE with the gfx950 correction of MI355X_MICROARCH.md -
+FETCH_SIZE counts half of a wide streaming read - and the SQ counters of the persistent kernel per wave and substep).
+usage: python tools/pmc_collect.py gpurun_out/prof_<tag> <tag> [substeps=300] [waves=2048]"""
+import csv, glob, json, shutil, sys
+from collections import defaultdict
+from pathlib import Path
+
+src, tag = Path(sys.argv[1]), sys.argv[2]
+nsub = int(sys.argv[3]) if len(sys.argv) > 3 else 300
+waves = int(sys.argv[4]) if len(sys.argv) > 4 else 2048
+root = Path(__file__).resolve().parents[1]
+prof = root / "profiles"
+
+
+def counters(d):
+    out = defaultdict(lambda: defaultdict(float)); launches = defaultdict(set)
+    for f in glob.glob(str(src / d / "*" / "*counter_collection.csv")):
+        for r in csv.DictReader(open(f)):
+            k = r["Kernel_Name"].split("(")[0].split("<")[0]
+            k = k[k.find("k_"):] if "k_" in k else k
+            out[k][r["Counter_Name"]] += float(r["Counter_Value"]); launches[k].add(r["Dispatch_Id"])
+    return out, {k: len(v) for k, v in launches.items()}
+
+
+stats = glob.glob(str(src / "trace" / "*" / "*kernel_stats.csv"))
+if stats:
+    shutil.copy(stats[0], prof / f"{tag}_kernel_stats.csv")
+fetch, nf = counters("pmc_fetch"); write, nw = counters("pmc_write"); sq, ns = counters("pmc_sq")
+summary = json.loads((prof / "pmc_summary.json").read_text()) if (prof / "pmc_summary.json").exists() else {}
+for k in sorted(set(fetch) | set(write)):
+    f = fetch[k].get("FETCH_SIZE", 0.0) / max(nf.get(k, 1), 1); w = write[k].get("WRITE_SIZE", 0.0) / max(nw.get(k, 1), 1)
+    summary[k] = {"fetch_kb_per_launch": f, "write_kb_per_launch": w, "hbm_bytes_per_launch": (2 * f + w) * 1024, "launches": nf.get(k, 0)}
+for k, v in sq.items():
+    if "k_env_step_mf" in k:
+        n = max(ns.get(k, 1), 1) * waves * nsub
+        summary["_sq_per_wave_per_substep"] = {c: round(x / n, 1) for c, x in sorted(v.items())}
+        summary["_sq_per_wave_per_substep"]["note"] = (f"{tag}: SQ counters of k_env_step_mf divided by (launches x {waves} waves x {nsub} substeps); "
+                                                       "*_CYCLES / ACTIVE / WAIT in units of 4 clocks")
+summary["_note"] = (f"{tag}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_* in separate passes (with --kernel-trace only), python3 bench.py --steps 1 "
+                    "--warmup 0 --no-cpu-baseline (cfg3, 8192 envs); bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 per the gfx950 correction of "
+                    "MI355X_MICROARCH.md; k_env_step_mf: one launch = 300 substeps of 8192 envs (algorithmic 630 MB); narrow accesses are uncalibrated")
+(prof / "pmc_summary.json").write_text(json.dumps(summary, indent=1))
+print(json.dumps({k: summary[k] for k in summary if "env_step" in k or k.startswith("_sq")}, indent=1))
