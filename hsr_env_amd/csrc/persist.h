@@ -383,6 +383,9 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
                                 const float *Ei2 = lds + (size_t)(it2 >> 14) * L.envf;
                                 mg -= gaddr(pk_g1(pk2), Ei2)[15] + gaddr(pk_g2(pk2), Ei2)[15];
                             }
+#ifdef HSR_PHASE_TIMING
+                            if ((tid & (MW - 1)) == 0) atomicAdd(&s.phase_cyc[32 + 40 * 4096 + (it2 & 0x3fff)], 1ull);       // tools/exp_pairs.py: convex items per pair
+#endif
                             const bool have = d.x != 0.f || d.y != 0.f || d.z != 0.f;
                             bool still = have && mg > 0.f;
                             if (have && !still) {
@@ -395,7 +398,7 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
                                 int nsup = 0;
                                 const bool hit = mpr_penetration<MW>(H1, H2, m.mpr_tolerance, m.mpr_iterations, depth, dir, pos, sep, nsup);
 #ifdef HSR_PHASE_TIMING
-                                if ((tid & (MW - 1)) == 0) { atomicAdd(&sDbg[0], nsup); atomicAdd(&sDbg[1], 1); atomicMax(&sDbg[2], nsup); }
+                                if ((tid & (MW - 1)) == 0) { atomicAdd(&sDbg[0], nsup); atomicAdd(&sDbg[1], 1); atomicMax(&sDbg[2], nsup); atomicAdd(&s.phase_cyc[32 + 40 * 4096 + 512 + (it2 & 0x3fff)], 1ull); }
 #endif
                                 mg = 0.f;
                                 if ((tid & (MW - 1)) == 0) {
