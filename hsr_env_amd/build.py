@@ -10,9 +10,9 @@ OUT = HERE / "libhsrsim.so"
 HIPCC = "/opt/rocm/bin/hipcc"
 
 
-def build_lib(force: bool = False, verbose: bool = False, timing: bool = False) -> Path:
+def build_lib(force: bool = False, verbose: bool = False, timing: bool = False, life: bool = False) -> Path:
     """timing=True builds the diagnostic variant libhsrsim_timing.so (in-kernel phase stamps; never benchmarked)."""
-    out = HERE / "libhsrsim_timing.so" if timing else OUT
+    out = HERE / "libhsrsim_timing.so" if timing else HERE / "libhsrsim_life.so" if life else OUT
     deps = list((HERE / "csrc").glob("*")) + [HERE.parent / "include" / "hsrsim.h"]
     if not force and out.exists() and all(out.stat().st_mtime >= d.stat().st_mtime for d in deps):
         return out
@@ -20,6 +20,8 @@ def build_lib(force: bool = False, verbose: bool = False, timing: bool = False) 
            "-o", str(out), str(SRC)]
     if timing:
         cmd.append("-DHSR_PHASE_TIMING")
+    elif life:
+        cmd.append("-DHSR_BLOCK_LIFE")     # product kernel + two stamps per workgroup (tools/block_life.py)
     if verbose:
         cmd.append("-Rpass-analysis=kernel-resource-usage")
     subprocess.check_call(cmd)

@@ -34,6 +34,13 @@ __device__ __forceinline__ unsigned long long stamp_() {
 #define PHASE_T0() unsigned long long dc_[4] = {0, 0, 0, 0}; unsigned long long pt_[32] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long t_prev_ = stamp_(); const unsigned long long t_first_ = t_prev_, r_first_ = __builtin_amdgcn_s_memrealtime()
 #define PHASE(idx) do { const unsigned long long t_now_ = stamp_(); pt_[idx] += t_now_ - t_prev_; t_prev_ = t_now_; } while (0)
 #define PHASE_FLUSH() do { if (tid == 0) { if (blockIdx.x < 8192) { unsigned long long *bt_ = s.phase_cyc + 32 + 40 * blockIdx.x; _Pragma("unroll") for (int i_ = 0; i_ < 32; i_++) bt_[8 + i_] = pt_[i_]; bt_[4] = dc_[0]; bt_[5] = dc_[1]; bt_[6] = dc_[2]; bt_[7] = dc_[3]; bt_[0] = r_first_; bt_[1] = __builtin_amdgcn_s_memrealtime(); bt_[2] = __builtin_amdgcn_s_getreg(63492); bt_[3] = __builtin_amdgcn_s_getreg(63508); } atomicAdd(&s.phase_cyc[26], stamp_() - t_first_); atomicAdd(&s.phase_cyc[27], __builtin_amdgcn_s_memrealtime() - r_first_); _Pragma("unroll") for (int i_ = 0; i_ < 26; i_++) atomicAdd(&s.phase_cyc[i_], pt_[i_]); } } while (0)
+#elif defined(HSR_BLOCK_LIFE)
+// second diagnostic build (libhsrsim_life.so, tools/block_life.py): only the (start, end) stamps of every workgroup and the event
+// counters, so the register allocation and the timing of the product kernel are kept
+#define PHASE_T0() unsigned long long dc_[4] = {0, 0, 0, 0}; const unsigned long long r_first_ = __builtin_amdgcn_s_memrealtime()
+#define DBGCNT(i, v) do { dc_[i] += (v); } while (0)
+#define PHASE(idx) do {} while (0)
+#define PHASE_FLUSH() do { if (tid == 0 && blockIdx.x < 8192) { unsigned long long *bt_ = s.phase_cyc + 32 + 40 * blockIdx.x; bt_[0] = r_first_; bt_[1] = __builtin_amdgcn_s_memrealtime(); bt_[4] = dc_[0]; bt_[5] = dc_[1]; bt_[6] = dc_[2]; bt_[7] = dc_[3]; } } while (0)
 #else
 #define PHASE_T0() do {} while (0)
 #define DBGCNT(i, v) do {} while (0)

@@ -1,0 +1,33 @@
+"""Diagnostic: workgroup lifetimes of the PRODUCT kernel (libhsrsim_life.so = product build + two stamps per workgroup), with
+the per-env Newton trip counts the product kernel keeps anyway.  The phase profile needs the heavier libhsrsim_timing.so
+(tools/block_times.py), whose stamps change the register allocation."""
+import ctypes as C, sys, numpy as np
+sys.path.insert(0, '.')
+from hsr_env_amd.compiler import load_config
+from hsr_env_amd import sim as hs
+from bench import sample_inputs
+m = load_config('cfg3'); n = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
+q0, goal = sample_inputs(m, n, 0, 0)
+sim = hs.BatchSim(m, n); sim.set_graph(False)
+sim.reset(qpos0=q0, mocap=goal)
+rng = np.random.default_rng(1)
+for k in range(3):
+    ctrl = rng.uniform(m.act_ctrlrange[:, 0], m.act_ctrlrange[:, 1], (n, m.nu)).astype(np.float32)
+    sim.step(ctrl, 300, m.body_id('block0'), 0.05)
+nb = n // 4
+L = sim._L
+L.hsr_batch_block_times.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong), C.c_int]
+buf = (C.c_ulonglong * (40 * nb))()
+L.hsr_batch_block_times(sim._b, buf, nb)
+a = np.frombuffer(buf, dtype=np.uint64).astype(np.int64).reshape(nb, 40)
+t0 = a[:, 0].min()
+life = (a[:, 1] - a[:, 0]) / 100.0
+print('blocks', nb, 'kernel span %.2f ms' % ((a[:, 1].max() - t0) / 1e5))
+pc = [0, 10, 25, 50, 75, 90, 99, 100]
+print('life percentiles us', pc, np.percentile(life, pc).round(0))
+print('p100 / p50 = %.2f   mean / p100 = %.2f' % (life.max() / np.median(life), life.mean() / life.max()))
+o = np.argsort(life)
+trips = a[:, 4] / 300.0
+print('Newton trips / substep: mean %.2f' % trips.mean())
+for nm, idx in (('slowest 10', o[-10:]), ('median 10', o[nb // 2 - 5: nb // 2 + 5])):
+    print(nm, 'life ms', (life[idx] / 1e3).round(1), '\n   trips', trips[idx].round(2), ' items', (a[idx, 6] / 300).round(1), ' nefc', (a[idx, 7] / 300).round(1))
