@@ -556,6 +556,21 @@ static int batch_init(hsr_batch *b, const hsr_model *m, int n_envs) {
         }
         if (b->persist_lds_bytes > 160 * 1024) ok = false;
         b->persist_ok = ok;
+        {   // trailing free bodies: link l owns exactly the dofs [nv - 6 (k + 1), nv - 6 k), lin then ang
+            const int *dn = m->i32("link_dofnum"), *lf = m->i32("link_free"), *da = m->i32("link_dofadr"), *dt = m->i32("dof_type"), *dl = m->i32("dof_link");
+            int nfb = 0;
+            for (int k = 0; 6 * (k + 1) <= d.nv; k++) {
+                const int a0 = d.nv - 6 * (k + 1), l = dl[a0];
+                bool fb = l > 0 && lf[l] && da[l] == a0 && dn[l] == 6;
+                for (int j = 0; fb && j < 6; j++) fb = dl[a0 + j] == l && dt[a0 + j] == (j < 3 ? DOF_FREE_LIN : DOF_FREE_ANG);
+                if (!fb) break;
+                nfb++;
+            }
+            if (nfb * 28 * (64 / b->group) > 4 * 48) nfb = 0;                  // the per-body accumulators live in the box-box polygon scratch
+            const char *nf = getenv("HSR_NFB");                                // diagnostic: HSR_NFB=0 keeps the per-contact assembly
+            if (nf && atoi(nf) < nfb) nfb = atoi(nf) < 0 ? 0 : atoi(nf);
+            b->dm.nfb = ok ? nfb : 0;
+        }
         const char *pe = getenv("HSR_PERSIST");
         b->persist = ok && !(pe && strcmp(pe, "0") == 0);
         if (ok && b->persist_lds_bytes > 48 * 1024)
@@ -640,6 +655,15 @@ extern "C" int hsr_batch_cap_counts(hsr_batch *b, unsigned long long *out) {
     HIPCHK(hipStreamSynchronize(b->stream));
     HIPCHK(hipMemcpy(out, b->ds.capstat, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     HIPCHK(hipMemset(b->ds.capstat, 0, 4 * sizeof(unsigned long long)));
+    return HSR_OK;
+}
+
+// per-env Newton iterations over the last (up to) 100 substeps of the previous persistent launch: what k_schedule packs by
+extern "C" int hsr_batch_newton_trips(hsr_batch *b, int32_t *out) {
+    if (!b || !out) return fail(HSR_EINVAL, "null argument");
+    HIPCHK(hipSetDevice(b->device));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    HIPCHK(hipMemcpy(out, b->ds.trips, (size_t)b->N * sizeof(int32_t), hipMemcpyDeviceToHost));
     return HSR_OK;
 }
 

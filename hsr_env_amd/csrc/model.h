@@ -32,6 +32,8 @@ struct DevModel {
     const float *geom_rec;            // [ngeom][32] seven float4: link type nvert meshadr | lpos rbound | lmat[0..3] | lmat[4..7] | lmat[8] size | aabb centre - | aabb half -
     int npair_pad;                    // npair rounded up to 32: row length of the per-env pair-count table
     int nstatic_geom;                 // leading geoms attached to the world link (placed once per launch by the persistent kernel)
+    int nfb;                          // free bodies whose six dofs (3 lin, 3 ang) form the tail of the dof vector, one after the other: their
+                                      // contacts with the world are assembled per body in the Newton Hessian (solve_body.inc); 0 = none / not applicable
     const float *act_gear, *act_kp, *act_ctrlrange, *act_forcerange;
 };
 

@@ -383,7 +383,7 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
                                 const float *Ei2 = lds + (size_t)(it2 >> 14) * L.envf;
                                 mg -= gaddr(pk_g1(pk2), Ei2)[15] + gaddr(pk_g2(pk2), Ei2)[15];
                             }
-#ifdef HSR_PHASE_TIMING
+#ifdef HSR_PAIR_HIST
                             if ((tid & (MW - 1)) == 0) atomicAdd(&s.phase_cyc[32 + 40 * 4096 + (it2 & 0x3fff)], 1ull);       // tools/exp_pairs.py: convex items per pair
 #endif
                             const bool have = d.x != 0.f || d.y != 0.f || d.z != 0.f;
@@ -398,7 +398,10 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
                                 int nsup = 0;
                                 const bool hit = mpr_penetration<MW>(H1, H2, m.mpr_tolerance, m.mpr_iterations, depth, dir, pos, sep, nsup);
 #ifdef HSR_PHASE_TIMING
-                                if ((tid & (MW - 1)) == 0) { atomicAdd(&sDbg[0], nsup); atomicAdd(&sDbg[1], 1); atomicMax(&sDbg[2], nsup); atomicAdd(&s.phase_cyc[32 + 40 * 4096 + 512 + (it2 & 0x3fff)], 1ull); }
+                                if ((tid & (MW - 1)) == 0) { atomicAdd(&sDbg[0], nsup); atomicAdd(&sDbg[1], 1); atomicMax(&sDbg[2], nsup); }
+#endif
+#ifdef HSR_PAIR_HIST
+                                if ((tid & (MW - 1)) == 0) atomicAdd(&s.phase_cyc[32 + 40 * 4096 + 512 + (it2 & 0x3fff)], 1ull);
 #endif
                                 mg = 0.f;
                                 if ((tid & (MW - 1)) == 0) {
@@ -446,6 +449,10 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
             if (c == my_quat_lane && my_type == DOF_FREE_ANG) { quat0.w = qposL[my_qadr]; quat0.x = qposL[my_qadr + 1]; quat0.y = qposL[my_qadr + 2]; quat0.z = qposL[my_qadr + 3]; }
         }
         wave_sync();             // qposL / link poses are read; region B may now be reused by the solver
+        // per-body Hessian accumulators of the solver: the box-box polygon scratch is dead from here to the next substep's collision
+        const int nfb = (EXACT && G == 32) ? m.nfb : 0;   // body b's columns are static tiles counted from nv = NK; with a single
+                                                           // block (G = 16) the per-contact assembly is as fast (measured), so it stays
+        float *fbK = poly + (size_t)g * 28 * nfb;
         float *lvbuf = reinterpret_cast<float *>(pcnt);       // the pair counts are consumed by the contact compaction (E2), before the first J v
         const int lvcap = ((m.npair_pad + 3) / 4) / 6;
         {

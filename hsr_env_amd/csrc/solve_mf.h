@@ -140,6 +140,8 @@ __global__ void __launch_bounds__(64, 2) k_solve_mf(DevModel m, DevState s, int 
             for (int k = 0; k < s.ngoal; k++) reach = reach && norm(body_point(s.goal_a[k]) - body_point(s.goal_b[k])) < s.goal_d[k];
         }
     }
+    constexpr int nfb = 0;                 // the per-substep chain keeps the per-contact Hessian assembly (no scratch for the per-body one)
+    float *fbK = nullptr;
 #define SOLVE_STORE_DIAG true
 #define PAIR_CNT(p) pair_cnt_[p]
 #include "solve_body.inc"

@@ -131,6 +131,9 @@ int hsr_batch_set_schedule(hsr_batch *b, int on);
  * beyond 64 per env, out[3] = (env, substep) pairs executed.  MuJoCo's own caps are nconmax=100 njmax=500
  * (hsr/models/world.xml:44); the compiled models carry smaller ones. */
 int hsr_batch_cap_counts(hsr_batch *b, unsigned long long *out /*[4]*/);
+/* Newton iterations every env ran over the last (up to) 100 substeps of its previous env-step launch: the hardness measure
+ * hsr_batch_set_schedule packs by (the solver's iteration count MuJoCo reports as mjData.solver_iter, summed). */
+int hsr_batch_newton_trips(hsr_batch *b, int32_t *out /*[n_envs]*/);
 
 /* diagnostics (meaningful only in the -DHSR_PHASE_TIMING build, libhsrsim_timing.so; tools/phase_timing.py,
  * tools/block_times.py): per-phase cycle sums of the last launches, and per-workgroup

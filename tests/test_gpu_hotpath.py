@@ -145,6 +145,65 @@ def test_setxml_model_single_substep(models):
     sim.close()
 
 
+def test_per_body_hessian_equals_per_contact_assembly(models, monkeypatch):
+    """cfg4 (three blocks): the Newton Hessian of the world <-> free-body contacts is assembled per body (one 6 x 6 matrix per
+    block, solve_body.inc body_hess); HSR_NFB=0 keeps the per-contact rank-1 updates.  Same states, one substep: both must agree
+    with each other far inside the parity tolerance, and with the oracle as every other single-substep test."""
+    m = models["cfg4"]
+    n = 128
+    rng = np.random.default_rng(2024)
+    q, v, ctrl = random_states(m, n, rng)
+    pre = oracle_rollout(m, q, v, ctrl, 60)
+    outs = []
+    for nfb in ("9", "0"):
+        monkeypatch.setenv("HSR_NFB", nfb)
+        sim = hs.BatchSim(m, n)
+        sim.set_debug(True)
+        sim.set_warmstart(np.array([s.qacc_warmstart for s in pre]))
+        sim.set_state(np.zeros(n), np.array([s.qpos for s in pre]), np.array([s.qvel for s in pre]))
+        outs.append((sim.step(ctrl, 1)[0], sim.get_field(hs.F_NCON).copy(), sim.newton_trips().copy()))
+        assert not sim.bad_state()[0].any()
+        sim.close()
+    (a, ncon, ta), (b, _, tb) = outs
+    dv = np.abs(a[:, m.nq:] - b[:, m.nq:]) / (1 + np.abs(b[:, m.nq:]))
+    assert int((ncon >= 8).sum()) > n // 2                      # the blocks do rest on the table: the per-body path is what ran
+    assert dv.max() < 2e-5, dv.max()                             # same minimiser, another summation order
+    assert np.abs(ta.astype(int) - tb.astype(int)).max() <= 1   # and the same number of Newton iterations (+-1 at a tolerance tie)
+    unexplained = []
+    for e in range(n):
+        o = pre[e]
+        o.step()
+        d = (np.abs(a[e, m.nq:] - o.qvel) / (1 + np.abs(o.qvel))).max()
+        if not d < 1e-4 and int(ncon[e]) == o.ncon:
+            unexplained.append((e, d))
+    assert not unexplained, unexplained
+
+
+def test_group_sums_are_identical_in_every_lane(models):
+    """Regression (round 2): a state of cfg4 (tests/golden/cfg4_lane_uniformity_state.npz, found by replaying the bench) in which
+    the lanes of one env disagreed in the last bit of a group sum - the compiler had contracted the product in gsum's argument
+    into the first butterfly addition - so that one lane left the line search alone, the broadcasts of the next iteration read
+    a disabled lane and the env ended in NaN.  One substep from that state must be finite and match the oracle."""
+    import pathlib
+    d = np.load(pathlib.Path(__file__).parent / "golden" / "cfg4_lane_uniformity_state.npz")
+    m = models["cfg4"]
+    n = 8
+    sim = hs.BatchSim(m, n)
+    q = np.tile(d["qpos"], (n, 1)); v = np.tile(d["qvel"], (n, 1))
+    sim.reset(qpos0=q, mocap=np.zeros((n, 3)))
+    sim.set_state(np.zeros(n), q, v)
+    sim.set_warmstart(np.tile(d["warm"], (n, 1)))
+    obs = sim.step(np.tile(d["ctrl"], (n, 1)), 1)[0]
+    assert np.isfinite(obs).all() and not sim.bad_state()[0].any()
+    assert (obs == obs[0]).all()                                 # the copies share waves pairwise: identical whatever the neighbour
+    o = OracleSim(m)
+    o.qpos[:] = d["qpos"]; o.qvel[:] = d["qvel"]; o.qacc_warmstart[:] = d["warm"]; o.ctrl[:] = d["ctrl"]
+    o.step()
+    assert (np.abs(obs[0, m.nq:] - o.qvel) / (1 + np.abs(o.qvel))).max() < 1e-4
+    assert np.abs(obs[0, :m.nq] - o.qpos).max() < 5e-6
+    sim.close()
+
+
 def test_model_wider_than_its_lane_group_uses_the_chain(models):
     """nq = 18 > 16 lanes (nv = 16): the persistent kernel holds qpos one entry per lane, so this model must run the
     per-substep chain (which indexes qpos through dof_qposadr) - and match the oracle."""

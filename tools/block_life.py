@@ -6,7 +6,9 @@ sys.path.insert(0, '.')
 from hsr_env_amd.compiler import load_config
 from hsr_env_amd import sim as hs
 from bench import sample_inputs
-m = load_config('cfg3'); n = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
+import os
+cfg = os.environ.get('HSR_CFG', 'cfg3')
+m = load_config(cfg); n = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
 q0, goal = sample_inputs(m, n, 0, 0)
 sim = hs.BatchSim(m, n); sim.set_graph(False)
 sim.reset(qpos0=q0, mocap=goal)
@@ -14,7 +16,8 @@ rng = np.random.default_rng(1)
 for k in range(3):
     ctrl = rng.uniform(m.act_ctrlrange[:, 0], m.act_ctrlrange[:, 1], (n, m.nu)).astype(np.float32)
     sim.step(ctrl, 300, m.body_id('block0'), 0.05)
-nb = n // 4
+epb = 4 if m.nv <= 16 else 2
+nb = n // epb
 L = sim._L
 L.hsr_batch_block_times.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong), C.c_int]
 buf = (C.c_ulonglong * (40 * nb))()

@@ -1,5 +1,5 @@
 """Diagnostic (timing build): which convex pairs reach the narrowphase of the persistent kernel, and which of them run MPR - the
-histograms are kept by the -DHSR_PHASE_TIMING build in the unused tail of its per-workgroup stamp buffer."""
+histograms are kept by a -DHSR_PHASE_TIMING -DHSR_PAIR_HIST build in the unused tail of its per-workgroup stamp buffer."""
 import ctypes as C, sys, numpy as np
 sys.path.insert(0, '.')
 from hsr_env_amd.compiler import load_config
