@@ -176,7 +176,7 @@ struct hsr_batch {
     bool persist = false;          // whole env-step in one persistent kernel (k_env_step_mf); HSR_PERSIST=0 disables
     bool persist_ok = false;       // the model fits the persistent kernel (lane maps, LDS, kinematic structure): set once at creation
     bool use_graph = true, profiling = false, debug_store = false;
-    bool schedule = false;         // re-pack the envs over the waves of the persistent kernel before every launch (HSR_SCHEDULE=1 / hsr_batch_set_schedule)
+    bool schedule = true;          // re-pack the envs over the waves of the persistent kernel before every launch (HSR_SCHEDULE=0 / hsr_batch_set_schedule turn it off)
     int *d_slot_env = nullptr;
     std::map<GraphKey, hipGraphExec_t> graphs;
     float last_total_ms = 0, last_kernel_ms[3] = {0, 0, 0};
@@ -520,7 +520,7 @@ static int batch_init(hsr_batch *b, const hsr_model *m, int n_envs) {
     if ((rc = dalloc(b, &s.trips, N))) return rc;
     if ((rc = dalloc(b, &b->d_slot_env, N + 64))) return rc;
     s.slot_env = nullptr;
-    { const char *sc = getenv("HSR_SCHEDULE"); b->schedule = sc && strcmp(sc, "1") == 0; }
+    { const char *sc = getenv("HSR_SCHEDULE"); b->schedule = !(sc && strcmp(sc, "0") == 0); }        // on unless HSR_SCHEDULE=0
     // cooperative solver geometry: 16 lanes per env when nv <= 16, else 32
     b->group = d.nv <= 16 ? 16 : 32;
     {
@@ -772,14 +772,16 @@ extern "C" int hsr_batch_set_mocap(hsr_batch *b, const float *mocap) { HIPCHK(hi
 extern "C" int hsr_batch_set_warmstart(hsr_batch *b, const float *w) { HIPCHK(hipSetDevice(b->device)); return to_device_soa(b, b->ds.warm, w, b->dm.nv); }
 extern "C" int hsr_batch_get_warmstart(hsr_batch *b, float *w) { HIPCHK(hipSetDevice(b->device)); return to_host_aos(b, w, b->ds.warm, b->dm.nv); }
 
-// Wave packing of the persistent kernel (optional, default off).  A launch ends with the wave that holds the hardest env (the one
-// that needs the most Newton iterations per substep), and a wave advances at the pace of its hardest env while the others idle: so
-// every one of the hardest quarter of the envs gets a wave of its own, filled up with three of the easiest envs (which leave the
-// Newton loop after one iteration), hardest waves dispatched first.  Hardness = the iterations an env ran in the last 100 substeps of its previous launch (DevState::trips).  Measured (r2,
-// cfg3 x 8192): with the packing computed from the state the env-step starts from, the launch is 15 % shorter; computed from the
-// previous env-step under the bench's freshly sampled ctrl it predicts too little (0..-3 %), and splitting the env-step into
-// re-packed launches costs more than it gains (every launch then waits for its own slowest wave: +10 %) - hence off by default;
-// a policy whose actions are correlated from one env-step to the next is the case it is kept for.
+// Wave packing of the persistent kernel (on by default; HSR_SCHEDULE=0 or hsr_batch_set_schedule(b, 0) keeps the identity packing).
+// A launch ends with the wave that holds the hardest env (the one that needs the most Newton iterations per substep), and a wave
+// advances at the pace of its hardest env while the others idle: so every one of the hardest envs gets a wave of its own, filled up
+// with the easiest envs (which leave the Newton loop after one iteration), hardest waves dispatched first.  Hardness = the
+// iterations an env ran in the last 100 substeps of its previous launch (DevState::trips).  Measured (r2, 8192 envs, the bench's
+// freshly sampled ctrl per env-step - the worst case for a predictor: corr 0.3 from one env-step to the next,
+// tools/exp_predict.py): cfg3 +0.5..1 % (one round of 2048 workgroups: only the packing counts), cfg4 +6 % (4096 workgroups over
+// 1792 slots: the dispatch order counts too); with the packing computed from the state the env-step starts from it would be 15 %,
+// and a policy whose actions are correlated from one env-step to the next comes closer to that.  Splitting the env-step into
+// re-packed launches costs more than it gains (every launch then waits for its own slowest wave: +10 %).
 // One workgroup sorts up to 8192 envs (bitonic, keys in LDS); larger batches are packed chunk by chunk.
 // Results do not depend on the packing: no value of an env is ever combined with another env's.
 enum { SCHED_CHUNK = 8192 };

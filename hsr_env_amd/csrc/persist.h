@@ -450,8 +450,13 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
         }
         wave_sync();             // qposL / link poses are read; region B may now be reused by the solver
         // per-body Hessian accumulators of the solver: the box-box polygon scratch is dead from here to the next substep's collision
-        const int nfb = (EXACT && G == 32) ? m.nfb : 0;   // body b's columns are static tiles counted from nv = NK; with a single
-                                                           // block (G = 16) the per-contact assembly is as fast (measured), so it stays
+        // body b's columns are static tiles counted from nv = NK; with a single block (G = 16) the per-contact assembly is as
+        // fast (measured: -DHSR_FB_ALL), so it stays
+#ifdef HSR_FB_ALL
+        const int nfb = EXACT ? m.nfb : 0;
+#else
+        const int nfb = (EXACT && G == 32) ? m.nfb : 0;
+#endif
         float *fbK = poly + (size_t)g * 28 * nfb;
         float *lvbuf = reinterpret_cast<float *>(pcnt);       // the pair counts are consumed by the contact compaction (E2), before the first J v
         const int lvcap = ((m.npair_pad + 3) / 4) / 6;

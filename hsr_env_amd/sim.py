@@ -269,7 +269,7 @@ class BatchSim:
         _check(self._L, self._L.hsr_batch_set_goals(self._b, n, a, b, d))
 
     def set_schedule(self, on: bool):
-        """Wave packing of the persistent kernel by env hardness (default off); never changes a result."""
+        """Wave packing of the persistent kernel by env hardness (default on); never changes a result."""
         _check(self._L, self._L.hsr_batch_set_schedule(self._b, int(on)))
 
     def cap_counts(self):

@@ -122,7 +122,7 @@ int hsr_batch_is_persistent(const hsr_batch *b);
  * per-pair contact counts (HSR_F_CONTACT), HSR_F_NCON / NEFC / NITER and HSR_F_QACC of every env's LAST substep (default off:
  * the fields then describe the last hsr_batch_forward).  Parity tests of the hot path's own narrowphase use it. */
 int hsr_batch_set_debug(hsr_batch *b, int on);
-/* wave packing of the persistent kernel (default off; HSR_SCHEDULE=1 turns it on at creation): before every launch the envs are re-distributed over the waves by the
+/* wave packing of the persistent kernel (default on; HSR_SCHEDULE=0 turns it off at creation): before every launch the envs are re-distributed over the waves by the
  * Newton iterations they needed at the end of their previous launch (hard envs one per wave, with the easiest as neighbours).
  * A pure scheduling decision: every env's result is bit-identical with it on or off. */
 int hsr_batch_set_schedule(hsr_batch *b, int on);

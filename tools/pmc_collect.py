@@ -15,7 +15,8 @@ prof = root / "profiles"
 
 def counters(d):
     out = defaultdict(lambda: defaultdict(float)); launches = defaultdict(set)
-    for f in glob.glob(str(src / d / "*" / "*counter_collection.csv")):
+    files = sorted(glob.glob(str(src / d / "*" / "*counter_collection.csv")), key=lambda f: Path(f).stat().st_mtime)
+    for f in files[-1:]:            # gpurun merges every call's outputs into the same directory: the newest run only
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"].split("(")[0].split("<")[0]
             k = k[k.find("k_"):] if "k_" in k else k
@@ -23,9 +24,9 @@ def counters(d):
     return out, {k: len(v) for k, v in launches.items()}
 
 
-stats = glob.glob(str(src / "trace" / "*" / "*kernel_stats.csv"))
+stats = sorted(glob.glob(str(src / "trace" / "*" / "*kernel_stats.csv")), key=lambda f: Path(f).stat().st_mtime)
 if stats:
-    shutil.copy(stats[0], prof / f"{tag}_kernel_stats.csv")
+    shutil.copy(stats[-1], prof / f"{tag}_kernel_stats.csv")
 fetch, nf = counters("pmc_fetch"); write, nw = counters("pmc_write"); sq, ns = counters("pmc_sq")
 summary = json.loads((prof / "pmc_summary.json").read_text()) if (prof / "pmc_summary.json").exists() else {}
 for k in sorted(set(fetch) | set(write)):
