@@ -284,6 +284,42 @@ def test_cap_counters_and_full_size(models):
     sim.close()
 
 
+def test_three_blocks_full_size_replay_of_the_bench_stays_finite(models):
+    """cfg4 at the bench's size and inputs (8192 envs, 3 blocks, ctrl ~ U(ctrlrange) per env-step, done envs reset), ten env-steps:
+    every env finite and not flagged bad, the caps counted over exactly the substeps run, no block through the floor or launched - the run
+    that exposed the lane-divergent group sum (env 3704, env-step 7).  The buffer caps may bite at most once in 1e5 env-substeps."""
+    import sys
+    from pathlib import Path
+    sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+    from bench import sample_inputs, GEOFENCE, STEPS_PER_ACTION
+    m = models["cfg4"]
+    n = 8192
+    q0, goal = sample_inputs(m, n, 0, 0)
+    rng = np.random.Generator(np.random.Philox(key=[1, 0]))
+    lo, hi = m.act_ctrlrange[:, 0].astype(np.float32), m.act_ctrlrange[:, 1].astype(np.float32)
+    sim = hs.BatchSim(m, n)
+    sim.reset(qpos0=q0, mocap=goal)
+    sim.cap_counts()
+    bid = m.body_id(m.block_body())
+    nsub = 0
+    for k in range(10):
+        ctrl = rng.uniform(lo, hi, (n, m.nu)).astype(np.float32)
+        obs, rew, done, ns = sim.step(ctrl, STEPS_PER_ACTION, bid, GEOFENCE)
+        nsub += int(ns.sum())
+        assert np.isfinite(obs).all(), (k, np.nonzero(~np.isfinite(obs).all(1))[0][:8])
+        assert not sim.bad_state()[0].any(), (k, np.nonzero(sim.bad_state()[0])[0][:8])
+        for a in m.free_joint_qadrs():
+            z = obs[:, a + 2]
+            assert (z > -0.05).all() and (z < 1.0).all(), (k, float(z.min()), float(z.max()))    # pushed off the pan it may fall to the floor; never through it, never launched
+            assert np.abs(np.linalg.norm(obs[:, a + 3:a + 7], axis=1) - 1).max() < 1e-4
+        rq, rg = sample_inputs(m, n, 2 + k, 0)
+        sim.reset(mask=np.asarray(done, np.uint8), qpos0=rq, mocap=rg)
+    c_con, c_row, c_item, total = sim.cap_counts()
+    assert total == nsub
+    assert c_item == 0 and c_con <= 1e-5 * total and c_row <= 2e-5 * total, (c_con, c_row, c_item, total)
+    sim.close()
+
+
 @pytest.mark.parametrize("cfg", ["cfg3", "cfg4"])
 def test_wave_packing_never_changes_a_result(models, cfg):
     """The persistent kernel can re-pack the envs over its waves before every launch (hard envs one per wave, easiest envs as
