@@ -187,9 +187,17 @@ struct hsr_batch {
 
 // the persistent kernel instantiations: (lanes per env, compile-time bound on nv)
 typedef void (*persist_fn)(const DevModel *, DevState, int, int, float, int);
-static persist_fn persist_kernel(int group, int nv) {
-    if (group == 16) return nv == 2 ? k_env_step_mf<16, 2, true> : (nv == 8 ? k_env_step_mf<16, 8, true> : (nv == 13 ? k_env_step_mf<16, 13, true> : k_env_step_mf<16, 16, false>));
-    return nv == 25 ? k_env_step_mf<32, 25, true> : k_env_step_mf<32, 32, false>;
+static persist_fn persist_kernel(int group, int nv, int ndense) {
+    // the compiled reference configurations get instances with nv and ndense at compile time; anything else the generic ones
+    if (group == 16) {
+        if (nv == 2 && ndense == 0) return k_env_step_mf<16, 2, true, 0>;            // cfg1: two orthogonal slides
+        if (nv == 8 && ndense == 0) return k_env_step_mf<16, 8, true, 0>;            // cfg2: the slides + one block
+        if (nv == 13 && ndense == 7) return k_env_step_mf<16, 13, true, 7>;          // cfg3: arm + block
+        if (nv == 13) return k_env_step_mf<16, 13, true>;                            // cupboard (ndense = nv) and others: ndense at run time
+        return k_env_step_mf<16, 16, false>;
+    }
+    if (nv == 25 && ndense == 7) return k_env_step_mf<32, 25, true, 7>;
+    return k_env_step_mf<32, 32, false>;
 }
 
 template <typename T>
@@ -574,13 +582,13 @@ static int batch_init(hsr_batch *b, const hsr_model *m, int n_envs) {
         const char *pe = getenv("HSR_PERSIST");
         b->persist = ok && !(pe && strcmp(pe, "0") == 0);
         if (ok && b->persist_lds_bytes > 48 * 1024)
-            HIPCHK(hipFuncSetAttribute((const void *)persist_kernel(b->group, d.nv), hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->persist_lds_bytes));
+            HIPCHK(hipFuncSetAttribute((const void *)persist_kernel(b->group, d.nv, d.ndense), hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->persist_lds_bytes));
     }
     if (getenv("HSR_DEBUG") && b->persist_ok) {
         int pb = -1;
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&pb, persist_kernel(b->group, d.nv), 64, b->persist_lds_bytes);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&pb, persist_kernel(b->group, d.nv, d.ndense), 64, b->persist_lds_bytes);
         hipFuncAttributes fb;
-        if (hipFuncGetAttributes(&fb, (const void *)persist_kernel(b->group, d.nv)) == hipSuccess)
+        if (hipFuncGetAttributes(&fb, (const void *)persist_kernel(b->group, d.nv, d.ndense)) == hipSuccess)
             fprintf(stderr, "[hsrsim] k_env_step_mf<%d>: regs %d, static LDS %zu, dyn LDS %zu, scratch %zu -> %d workgroups per CU\n", b->group, fb.numRegs, fb.sharedSizeBytes, b->persist_lds_bytes, fb.localSizeBytes, pb);
     }
     {
@@ -840,7 +848,7 @@ extern "C" int hsr_batch_step_dev(hsr_batch *b, const float *d_ctrl, int n_subst
         if (sched) hipLaunchKernelGGL(k_schedule, dim3((N + SCHED_CHUNK - 1) / SCHED_CHUNK), dim3(1024), 0, st, b->ds, epb, b->d_slot_env);
         DevState dsl = b->ds;
         dsl.slot_env = sched ? b->d_slot_env : nullptr;
-        hipLaunchKernelGGL(persist_kernel(b->group, b->dm.nv), dim3((N + epb - 1) / epb), dim3(64), b->persist_lds_bytes, st, (const DevModel *)b->d_dm, dsl, n_substeps, goal_body, geofence, b->debug_store ? 1 : 0);
+        hipLaunchKernelGGL(persist_kernel(b->group, b->dm.nv, b->dm.ndense), dim3((N + epb - 1) / epb), dim3(64), b->persist_lds_bytes, st, (const DevModel *)b->d_dm, dsl, n_substeps, goal_body, geofence, b->debug_store ? 1 : 0);
         if (b->profiling) { hipEvent_t ev; hipEventCreate(&ev); hipEventRecord(ev, st); b->kev.push_back(ev); }   // slots 0,1 empty; slot 2 = the persistent kernel
     } else if (b->use_graph && !b->profiling && n_substeps > 0) {
         GraphKey key{n_substeps, goal_body, geofence};

@@ -42,13 +42,14 @@ template <int G> struct PersistLayout {
 
 // NVT: compile-time bound on nv (nv <= NVT <= G); the matrix loops of the solver run to NVT instead of G
 // EXACT: nv == NVT, known at compile time (the `j < nv` guards of the unrolled matrix loops fold away)
-template <int G, int NVT, bool EXACT>
+// NDT (EXACT only, else -1): ndense at compile time - the dofs from NDT on never couple to another dof in M (free bodies)
+template <int G, int NVT, bool EXACT, int NDT = -1>
 __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restrict__ mp, DevState s, int n_substeps, int goal_body, float geofence, int flags) {
     // the ~90 model fields stay in (constant-cached) memory and are read where they are used, instead of sitting in - and
     // spilling from - SGPRs for the whole launch
     const DevModel &m = *mp;
     extern __shared__ __align__(16) float lds[];
-    constexpr int EPB = 64 / G, NK = NVT;
+    constexpr int EPB = 64 / G, NK = NVT, NDK = EXACT ? NDT : -1;
     const PersistLayout<G> L(m.njmax, s.kstride, m.npair_pad, m.nlink, m.ngeom, m.nstatic_geom);
     const int tid0 = threadIdx.x;
     const int N = s.N, nv = EXACT ? NVT : m.nv, nq = m.nq, R = L.R, MS = L.MS;

@@ -171,6 +171,31 @@ template <int G, int NK = G> __device__ __forceinline__ bool chol_g(float (&row)
     });
     return ok;
 }
+// The same factorisation for a matrix whose columns j >= ND (compile time) have no off-diagonal entries at all - the inertia
+// matrix M and M + h D of a robot followed by free bodies with principal-axis inertia: ND pivot steps with updates of the first ND
+// rows only, and every tail lane takes the reciprocal root of its own diagonal entry (diag: lane c's M[c][c]; 1 for the padding lanes).
+template <int G, int NK, int ND> __device__ __forceinline__ bool chol_g_tail(float (&row)[G], float &invd, float diag, int c) {
+    bool ok = true;
+    invd = 1.f;
+    static_for<0, ND>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        float ajj = gbcast_after_asm<G, j>(row[j]);
+        if (!(ajj >= HSR_MINVAL)) { ok = false; ajj = 1.f; }
+        const float inv = __builtin_amdgcn_rsqf(ajj);
+        const float lcj = row[j] * inv;
+        if (c == j) invd = inv;
+        row[j] = lcj;
+        const float nl = -lcj;
+        const BcSrc<G> bl = bc_prepare<G>(lcj);
+        static_for<j + 1, ND>([&](auto ic) { constexpr int i = decltype(ic)::value; fmac_bcast<G, i, bc_first<G, i, j + 1>()>(row[i], nl, bl); });
+    });
+    if (c >= ND) {
+        float ajj = diag;
+        if (!(ajj >= HSR_MINVAL)) { ok = false; ajj = 1.f; }
+        invd = __builtin_amdgcn_rsqf(ajj);
+    }
+    return ok;
+}
 // elliptic cone at residual x: cost, gradient g, and the Hessian in the form
 //   H = diag(dw) + Dm gn gn^T - k3 u u^T      (zone 0 top: all zero; 1 bottom: dw = D; 2 middle)
 struct ConeOut { float cost, Dm, k3; int zone; float g[6], dw[6], gn[6], u[6]; };

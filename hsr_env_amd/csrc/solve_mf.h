@@ -58,6 +58,28 @@ template <int G, int NK = G> __device__ __forceinline__ float chol_solve_mf(cons
     return x;
 }
 
+// ... and the two substitutions with such a factor (chol_g_tail): ND dependent steps each; a tail lane solves its own equation
+template <int G, int NK, int ND> __device__ __forceinline__ float chol_solve_tail(const float (&row)[G], float invd, float b, int c) {
+    float nlo[ND > 0 ? ND : 1];
+#pragma unroll
+    for (int k = 0; k < ND; k++) nlo[k] = (k < c && c < ND) ? -row[k] : 0.f;
+    float sacc = b, y = 0.f;
+    static_for<0, ND>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        const float t = sacc * invd;
+        if (c == j) y = t;
+        fmac_bcast<G, j, true>(sacc, nlo[j], bc_prepare<G>(t));
+    });
+    float x = 0.f;
+    if (c >= ND) x = b * invd * invd;
+    static_for<0, ND>([&](auto jc) {
+        constexpr int j = ND - 1 - decltype(jc)::value;
+        const float tot = (ND <= 16) ? gsum<16>(nlo[j] * x) : gsum<G>(nlo[j] * x);      // the coupled dofs sit in the first DPP row
+        if (c == j) x = (y + tot) * invd;
+    });
+    return x;
+}
+
 template <int G>
 __global__ void __launch_bounds__(64, 2) k_solve_mf(DevModel m, DevState s, int mode, int goal_body, float geofence, int debug) {
     extern __shared__ __align__(16) float lds[];
@@ -140,6 +162,7 @@ __global__ void __launch_bounds__(64, 2) k_solve_mf(DevModel m, DevState s, int 
             for (int k = 0; k < s.ngoal; k++) reach = reach && norm(body_point(s.goal_a[k]) - body_point(s.goal_b[k])) < s.goal_d[k];
         }
     }
+    constexpr int NDK = -1;                // ... and the run-time ndense
     constexpr int nfb = 0;                 // the per-substep chain keeps the per-contact Hessian assembly (no scratch for the per-body one)
     float *fbK = nullptr;
 #define SOLVE_STORE_DIAG true
