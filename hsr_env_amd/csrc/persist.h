@@ -176,15 +176,15 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
             Kin2 kin;
             kin.stageA(lds + L.oKin, m.nlink, c, qposL, recL);
             wave_sync();
-            PHASE(26);
+            PHASE_K(26);
             kin.stageB(m.maxdepth, recL, poseL);
             wave_sync();
-            PHASE(27);
+            PHASE_K(27);
             kin.stageC(lds + L.oKin, sDofLink, nv, poseL, qvelL, kAng, kLin, kAnc, dwL);
             wave_sync();
-            PHASE(28);
+            PHASE_K(28);
             kin.stageD((c < m.nlink && c < NLMAX) ? sMask[c] : 0, qvelL, dwL, recL);
-            PHASE(29);
+            PHASE_K(29);
             kin.stageE(m.gravz, lk);
             wave_sync();
         }
@@ -218,7 +218,7 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
             for (int i = c; i < 9 * m.nlink; i += G) s.xmat[(size_t)i * N + e] = poseL[12 * (i / 9) + i % 9];
             for (int i = c; i < 6 * m.nlink; i += G) { const int l = (i % (3 * m.nlink)) / 3; s.lvel[(size_t)i * N + e] = recL[12 * l + (i < 3 * m.nlink ? 0 : 3) + i % 3]; }   // link w, then v(origin)
         }
-        PHASE(31);
+        PHASE_K(31);
         // ---------------- C: collision
         // G: lane = geom, world placement of every geom once per substep (LDS, next to the link poses)
         // 1: lane = candidate pair of its own env, bounding spheres; survivors -> workgroup candidate list (wave ballots)
@@ -245,7 +245,7 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
             }
             for (int p0 = 0; p0 < m.npair_pad / 4; p0 += G) { const int p = p0 + c; if (p < m.npair_pad / 4) reinterpret_cast<int *>(pcnt)[p] = 0; }
             wave_sync();
-            PHASE(30);
+            PHASE_K(30);
             const float4 *pg4 = reinterpret_cast<const float4 *>(m.pair_geo);
             const unsigned *sPair = reinterpret_cast<const unsigned *>(lds + L.oPair);
             unsigned short *sCand = reinterpret_cast<unsigned short *>(poly);      // 128 entries in the box-box polygon scratch (dead during the culls)
@@ -376,6 +376,7 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
                             // separation is left after the geoms' moves since (upper bounds, geom cache slot 15): while it is
                             // positive the pair is still separated along d and nothing is scanned; otherwise both hulls are scanned
                             // along d and the margin is refreshed; MPR runs only when d no longer separates
+                            PHASE_M(26);
                             float *sx = s.sepax + (size_t)(4 * (it2 & 0x3fff)) * N + sEnv[it2 >> 14];
                             const v3 d = mk3(sx[0], sx[N], sx[2 * (size_t)N]);
                             float mg = sx[3 * (size_t)N];
@@ -389,11 +390,13 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
 #endif
                             const bool have = d.x != 0.f || d.y != 0.f || d.z != 0.f;
                             bool still = have && mg > 0.f;
+                            PHASE_M(27);
                             if (have && !still) {
                                 const float gap = -dot(support<MW>(H1, d) - support<MW>(H2, -d), d);
                                 still = gap > 1e-7f;
                                 mg = still ? 0.98f * gap : 0.f;
                             }
+                            PHASE_M(28);
                             if (!still) {
                                 float depth; v3 dir, pos, sep;
                                 int nsup = 0;
@@ -404,6 +407,7 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
 #ifdef HSR_PAIR_HIST
                                 if ((tid & (MW - 1)) == 0) atomicAdd(&s.phase_cyc[32 + 40 * 4096 + 512 + (it2 & 0x3fff)], 1ull);
 #endif
+                                PHASE_M(29);
                                 mg = 0.f;
                                 if ((tid & (MW - 1)) == 0) {
                                     if (hit) { o2.add(pos, dir, -depth); sep = mk3(0, 0, 0); }
@@ -412,6 +416,7 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
                             }
                             if ((tid & (MW - 1)) == 0) sx[3 * (size_t)N] = mg;
                             if ((tid & (MW - 1)) == 0) *cntp = (unsigned char)o2.cnt;
+                            PHASE_M(30);
                         }
                     }
                 }

@@ -49,6 +49,14 @@ __device__ __forceinline__ unsigned long long stamp_() {
 #define PHASE(idx) do {} while (0)
 #define PHASE_FLUSH() do {} while (0)
 #endif
+// the six spare stamps: the kinematics stages by default, the inside of the MPR section with -DHSR_MPR_PROFILE (timing build)
+#ifdef HSR_MPR_PROFILE
+#define PHASE_K(idx) do {} while (0)
+#define PHASE_M(idx) PHASE(idx)
+#else
+#define PHASE_K(idx) PHASE(idx)
+#define PHASE_M(idx) do {} while (0)
+#endif
 // DPP controls (gfx90a+): row_shr:n = 0x110+n, row_ror:n = 0x120+n, row_newbcast:n = 0x150+n; a "row" is 16 lanes,
 // exactly one 16-lane env group, so these are single full-rate VALU modifiers instead of ds_bpermute round trips
 template <int CTRL, bool ZERO_OOB> __device__ __forceinline__ float dpp_f(float v) {

@@ -15,7 +15,7 @@ sim.reset(qpos0=q0, mocap=goal)
 rng = np.random.default_rng(1)
 for k in range(3):
     ctrl = rng.uniform(m.act_ctrlrange[:, 0], m.act_ctrlrange[:, 1], (n, m.nu)).astype(np.float32)
-    sim.step(ctrl, 300, m.body_id('block0'), 0.05)
+    sim.step(ctrl, 300, m.body_id(m.block_body()) if m.block_body() else -1, 0.05)
 epb = 4 if m.nv <= 16 else 2
 nb = n // epb
 L = sim._L
