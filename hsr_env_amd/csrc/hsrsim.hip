@@ -452,8 +452,8 @@ static int batch_init(hsr_batch *b, const hsr_model *m, int n_envs) {
         d.nstatic_geom = 0;
         while (d.nstatic_geom < d.ngeom && gl[d.nstatic_geom] == 0) d.nstatic_geom++;
     }
-    d.npair_pad = (d.npair + 31) & ~31;
-    if (d.npair_pad == 0) d.npair_pad = 32;
+    d.npair_pad = (d.npair + 7) & ~7;
+    if (d.npair_pad == 0) d.npair_pad = 8;
     {   // derived tables: per-pair record and dof -> actuator map
         const int *g1 = m->i32("pair_geom1"), *g2 = m->i32("pair_geom2"), *cd = m->i32("pair_condim"), *gl = m->i32("geom_link"), *ad = m->i32("act_dof");
         const double *fr = m->f64("pair_friction"), *sr = m->f64("pair_solref"), *si = m->f64("pair_solimp"), *iw = m->f64("geom_invweight");

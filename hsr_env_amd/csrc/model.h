@@ -30,7 +30,7 @@ struct DevModel {
     const float *pair_rec;            // [npair][16]: dim l1 l2 tran fri[5] solref[2] solimp[5]
     const float *pair_geo;            // [npair][8]  g1 + 256 (geom1 is a plane)  g2  rbound1  rbound2 | fn slot maxcnt type1 (two float4 loads)
     const float *geom_rec;            // [ngeom][32] seven float4: link type nvert meshadr | lpos rbound | lmat[0..3] | lmat[4..7] | lmat[8] size | aabb centre - | aabb half -
-    int npair_pad;                    // npair rounded up to 32: row length of the per-env pair-count table
+    int npair_pad;                    // npair rounded up to 8: row length of the per-env pair-count table
     int nstatic_geom;                 // leading geoms attached to the world link (placed once per launch by the persistent kernel)
     int nfb;                          // free bodies whose six dofs (3 lin, 3 ang) form the tail of the dof vector, one after the other: their
                                       // contacts with the world are assembled per body in the Newton Hessian (solve_body.inc); 0 = none / not applicable

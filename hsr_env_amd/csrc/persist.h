@@ -19,7 +19,7 @@
 #include "solve_mf.h"
 
 template <int G> struct PersistLayout {
-    int R, MS, oRows, oCnt, oB, envf, oPoly, oKin, oPair, oGeomC, oGeomS, total;
+    int R, MS, oRows, oCnt, oB, envf, oPoly, oKin, oPair, oGeomC, oGeomS, oLinkTab, total;
     __host__ __device__ PersistLayout(int rows, int kstride, int npair_pad, int nlink, int ngeom, int nstatic) {
         R = rows; MS = G + 1;
         int a = 5 * R > kstride ? 5 * R : kstride;                            // row scalars / kin record
@@ -36,7 +36,8 @@ template <int G> struct PersistLayout {
         oPair = oKin + KIN2_FLOATS * nlink;                                     // packed sphere-cull record per candidate pair (one dword), rows of 8
         oGeomC = oPair + ((npair_pad + 7) & ~7);                                // narrowphase constants of every geom (8 floats each)
         oGeomS = oGeomC + 8 * ngeom;                                            // world placements of the static geoms (16 floats each)
-        total = oGeomS + 16 * nstatic;
+        oLinkTab = oGeomS + 16 * nstatic;                                       // chain dof mask and mass of every link
+        total = (oLinkTab + 2 * nlink + 3) & ~3;
     }
 };
 
@@ -77,15 +78,17 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
     (void)rD; (void)rAref; (void)rJar; (void)rJv; (void)rDw; (void)kLin; (void)kAnc; (void)lk; (void)pcnt; (void)M; (void)con; \
     (void)poseL; (void)recL; (void)qvelL; (void)poly; (void)isdof; (void)e; (void)in_range;
     int bad_acc = 0, trips_acc = 0;
-    __shared__ int sParent[32], sMask[NLMAX];
+    // every byte counts: cfg4's 20.6 KB per workgroup were 144 B above an eighth of the CU's LDS (7 instead of 8 workgroups per CU)
+    __shared__ signed char sParent[32];
+    int *sMask = reinterpret_cast<int *>(lds + L.oLinkTab);
+    float *sMass = lds + L.oLinkTab + m.nlink;
     __shared__ unsigned short sItems[64 * (64 / G)];   // narrowphase work items: at most 64 per env, processed 64 at a time
     __shared__ unsigned char sMpr[64];
 #ifdef HSR_PHASE_TIMING
     __shared__ int sDbg[4];
     if (tid0 < 4) sDbg[tid0] = 0;
 #endif
-    __shared__ float sMass[NLMAX];
-    if (tid0 < nv) sParent[tid0] = m.dof_parent[tid0];
+    if (tid0 < nv) sParent[tid0] = (signed char)m.dof_parent[tid0];
     if (tid0 < m.nlink && tid0 < NLMAX) { sMask[tid0] = m.link_dofmask[tid0]; sMass[tid0] = m.link_mass[tid0]; }
     __shared__ unsigned char sDofLink[32];
     __shared__ int sEnv[64 / G];                       // env index of every lane group of this workgroup (wave packing: DevState::slot_env)
