@@ -320,6 +320,31 @@ def test_three_blocks_full_size_replay_of_the_bench_stays_finite(models):
     sim.close()
 
 
+def test_wave_packing_with_a_ragged_batch(models):
+    """The packing sorts 8192 envs per chunk: a batch that is neither a multiple of the chunk nor of the envs per wave (8192 + 13)
+    must be covered exactly once - every env stepped, bit-identical with the packing off."""
+    m = models["cfg3"]
+    n = 8192 + 13
+    rng = np.random.default_rng(5)
+    q = np.tile(m.qpos0, (n, 1)); a = m.free_joint_qadrs()[0]
+    q[:, a] = rng.uniform(-0.1, 0.1, n); q[:, a + 1] = rng.uniform(-0.2, 0.2, n)
+    goal = np.tile([0.3, 0.0, 0.422], (n, 1))
+    ctrls = [rng.uniform(m.act_ctrlrange[:, 0], m.act_ctrlrange[:, 1], (n, m.nu)).astype(np.float32) for _ in range(3)]
+    outs = []
+    for schedule in (False, True):
+        sim = hs.BatchSim(m, n)
+        sim.set_schedule(schedule)
+        sim.reset(qpos0=q, mocap=goal)
+        res = [sim.step(c, 40, m.body_id("block0"), 0.03) for c in ctrls]
+        outs.append(res)
+        assert (res[-1][3] == 40).all() or res[-1][2].any()           # every env ran its substeps (or latched done)
+        sim.close()
+    for k in range(len(ctrls)):
+        for x, y in zip(outs[0][k], outs[1][k]):
+            assert np.array_equal(x, y), f"packing changed a result in env-step {k}"
+    assert not (outs[1][-1][0][:, :m.nq] == q).all(axis=1).any()     # no env was left unstepped
+
+
 @pytest.mark.parametrize("cfg", ["cfg3", "cfg4"])
 def test_wave_packing_never_changes_a_result(models, cfg):
     """The persistent kernel can re-pack the envs over its waves before every launch (hard envs one per wave, easiest envs as
