@@ -176,6 +176,7 @@ struct hsr_batch {
     bool persist = false;          // whole env-step in one persistent kernel (k_env_step_mf); HSR_PERSIST=0 disables
     bool persist_ok = false;       // the model fits the persistent kernel (lane maps, LDS, kinematic structure): set once at creation
     bool use_graph = true, profiling = false, debug_store = false;
+    int test_hooks = 0;            // hsr_batch_set_debug bits 1.. : force rarely taken solver branches (tests only)
     bool schedule = true;          // re-pack the envs over the waves of the persistent kernel before every launch (HSR_SCHEDULE=0 / hsr_batch_set_schedule turn it off)
     int *d_slot_env = nullptr;
     std::map<GraphKey, hipGraphExec_t> graphs;
@@ -643,7 +644,7 @@ extern "C" int hsr_batch_set_persistent(hsr_batch *b, int on) {
     return b->persist ? 1 : 0;
 }
 extern "C" int hsr_batch_is_persistent(const hsr_batch *b) { return b->persist ? 1 : 0; }
-extern "C" int hsr_batch_set_debug(hsr_batch *b, int on) { b->debug_store = on != 0; return HSR_OK; }
+extern "C" int hsr_batch_set_debug(hsr_batch *b, int on) { if (!b) return fail(HSR_EINVAL, "null batch"); b->debug_store = (on & 1) != 0; b->test_hooks = on & 6; return HSR_OK; }
 extern "C" int hsr_batch_set_schedule(hsr_batch *b, int on) { b->schedule = on != 0; return HSR_OK; }
 extern "C" int hsr_batch_set_goals(hsr_batch *b, int n, const int *body_a, const int *body_b, const float *dist) {
     if (!b || n < 0 || n > 4 || (n > 0 && (!body_a || !body_b || !dist))) return fail(HSR_EINVAL, "hsr_batch_set_goals: 0..4 terms");
@@ -848,7 +849,7 @@ extern "C" int hsr_batch_step_dev(hsr_batch *b, const float *d_ctrl, int n_subst
         if (sched) hipLaunchKernelGGL(k_schedule, dim3((N + SCHED_CHUNK - 1) / SCHED_CHUNK), dim3(1024), 0, st, b->ds, epb, b->d_slot_env);
         DevState dsl = b->ds;
         dsl.slot_env = sched ? b->d_slot_env : nullptr;
-        hipLaunchKernelGGL(persist_kernel(b->group, b->dm.nv, b->dm.ndense), dim3((N + epb - 1) / epb), dim3(64), b->persist_lds_bytes, st, (const DevModel *)b->d_dm, dsl, n_substeps, goal_body, geofence, b->debug_store ? 1 : 0);
+        hipLaunchKernelGGL(persist_kernel(b->group, b->dm.nv, b->dm.ndense), dim3((N + epb - 1) / epb), dim3(64), b->persist_lds_bytes, st, (const DevModel *)b->d_dm, dsl, n_substeps, goal_body, geofence, (b->debug_store ? 1 : 0) | b->test_hooks);
         if (b->profiling) { hipEvent_t ev; hipEventCreate(&ev); hipEventRecord(ev, st); b->kev.push_back(ev); }   // slots 0,1 empty; slot 2 = the persistent kernel
     } else if (b->use_graph && !b->profiling && n_substeps > 0) {
         GraphKey key{n_substeps, goal_body, geofence};

@@ -56,6 +56,7 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
     const int N = s.N, nv = EXACT ? NVT : m.nv, nq = m.nq, R = L.R, MS = L.MS;
     const int mode = 1, debug = 0;
     const bool dbg_store = flags & 1;          // introspection: contact counts / solver counters of each env's last substep go to global memory
+    const bool hook_jv_per_contact = flags & 2, hook_majorant = flags & 4;      // tests: force the J v per contact / the PSD-majorant Newton step
     int cap_con = 0, cap_row = 0, cap_item = 0, nsub_run = 0;      // cap statistics of this lane's env (lane c == 0 reports)
     int own_trips = 0;                                              // Newton iterations of this lane's env over its last (up to) 100 substeps
     // everything derived from the lane id is declared through this macro: once for the prologue, once per substep from a

@@ -257,8 +257,9 @@ class BatchSim:
     def is_persistent(self) -> bool:
         return bool(self._L.hsr_batch_is_persistent(self._b))
 
-    def set_debug(self, on: bool):
-        """Also store the contact counts / solver counters of each env's last substep during step() (persistent kernel)."""
+    def set_debug(self, on):
+        """Also store the contact counts / solver counters of each env's last substep during step() (persistent kernel).
+        `on` may be a bit mask: 1 = store, 2 / 4 = test hooks (J v per contact / PSD-majorant Newton steps), include/hsrsim.h."""
         _check(self._L, self._L.hsr_batch_set_debug(self._b, int(on)))
 
     def set_goals(self, terms):

@@ -179,6 +179,38 @@ def test_per_body_hessian_equals_per_contact_assembly(models, monkeypatch):
     assert not unexplained, unexplained
 
 
+@pytest.mark.parametrize("cfg", ["cfg3", "cfg4"])
+@pytest.mark.parametrize("hook", [2, 4])
+def test_rarely_taken_solver_branches(models, cfg, hook):
+    """Two branches of the Newton solver that ordinary states (almost) never take, forced through hsr_batch_set_debug's test
+    hooks: J v per contact (taken when an env's contacts involve more links than the link-velocity scratch holds) and the
+    PSD-majorant Hessian with its own line-search start (taken when the exact cone Hessian is not positive definite).  Both reach
+    the same minimiser: one substep must match the oracle as in every other single-substep test."""
+    m = models[cfg]
+    n = 64
+    rng = np.random.default_rng(31 + hook)
+    q, v, ctrl = random_states(m, n, rng)
+    pre = oracle_rollout(m, q, v, ctrl, 60)
+    sim = hs.BatchSim(m, n)
+    sim.set_debug(1 | hook)
+    sim.set_warmstart(np.array([s.qacc_warmstart for s in pre]))
+    sim.set_state(np.zeros(n), np.array([s.qpos for s in pre]), np.array([s.qvel for s in pre]))
+    obs = sim.step(ctrl, 1)[0]
+    ncon = sim.get_field(hs.F_NCON)
+    assert not sim.bad_state()[0].any()
+    assert int((ncon > 0).sum()) > n // 2
+    unexplained = []
+    for e in range(n):
+        o = pre[e]
+        o.step()
+        dq = np.abs(obs[e, :m.nq] - o.qpos).max()
+        dv = (np.abs(obs[e, m.nq:] - o.qvel) / (1 + np.abs(o.qvel))).max()
+        if not (dq < 5e-6 and dv < 1e-4) and int(ncon[e]) == o.ncon:
+            unexplained.append((e, dq, dv))
+    assert not unexplained, unexplained
+    sim.close()
+
+
 def test_group_sums_are_identical_in_every_lane(models):
     """Regression (round 2): a state of cfg4 (tests/golden/cfg4_lane_uniformity_state.npz, found by replaying the bench) in which
     the lanes of one env disagreed in the last bit of a group sum - the compiler had contracted the product in gsum's argument
