@@ -18,7 +18,7 @@
 #define HSR_LS_REL_FAR 0.05f
 #endif
 #ifndef HSR_LS_REL
-#define HSR_LS_REL 1e-3f        // relative stop of the exact line search: |phi'(alpha)| < HSR_LS_REL |phi'(0)|
+#define HSR_LS_REL 1e-2f        // relative stop of the exact line search: |phi'(alpha)| < HSR_LS_REL |phi'(0)|  (1e-3: same iteration counts, launch 2.6 % longer)
 #endif
 #ifdef HSR_PHASE_TIMING
 // diagnostic build only: stamp = one asm statement (s_memtime + its wait) fenced by sched_barriers, sums kept in
