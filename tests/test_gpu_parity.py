@@ -132,7 +132,7 @@ def test_single_substep_matches_oracle(models, cfg):
     sim.close()
 
 
-@pytest.mark.parametrize("cfg", ["cfg2", "cfg3", "cupboard"])
+@pytest.mark.parametrize("cfg", ["cfg1", "cfg2", "cfg3", "cfg4", "cupboard"])
 def test_env_step_300_matches_oracle(models, cfg):
     """A whole env-step (300 substeps): median |dobs| < 1e-4, 90th percentile < 2e-3 (contact
     dynamics amplify fp32 rounding over 300 steps; per-substep parity is the sharp test).  In the cupboard scene
