@@ -939,6 +939,10 @@ TEST_CONFIGS = {
                         set_xml=[("worldbody/body[@name='pan']/geom/friction", "0.5 0.005 0.0001"),
                                  ("actuator/position[@name='arm_lift_motor']/ctrllimited", "false")]),
     "nq18": dict(dofs=["slide_x", "slide_y", "arm_lift_joint", "arm_flex_joint"], n_blocks=2),
+    # sizes none of the reference configurations has: they run the GENERIC instances of the persistent kernel (nv and ndense at
+    # run time) - nv 11 in a 16-lane group, nv 23 in a 32-lane group
+    "nv11": dict(dofs=["slide_x", "slide_y", "arm_lift_joint", "arm_flex_joint", "wrist_roll_joint"], n_blocks=1),
+    "nv23": dict(dofs=["slide_x", "slide_y", "arm_lift_joint", "arm_flex_joint", "wrist_roll_joint"], n_blocks=3),
 }
 MODEL_DIR = Path(__file__).parent / "models"
 

@@ -211,6 +211,45 @@ def test_rarely_taken_solver_branches(models, cfg, hook):
     sim.close()
 
 
+@pytest.mark.parametrize("cfg", ["nv11", "nv23"])
+def test_generic_instances_of_the_persistent_kernel(models, cfg):
+    """The reference configurations run kernel instances with nv and ndense at compile time; any other model gets the generic
+    ones (k_env_step_mf<16, 16, false> / <32, 32, false>: loops to the lane-group size, run-time ndense, per-contact Hessian).
+    Five arm dofs + one block (nv 11) and + three blocks (nv 23): one substep against the oracle, then sixty substeps of the
+    persistent kernel against the per-substep chain."""
+    m = models[cfg]
+    n = 64
+    rng = np.random.default_rng(404)
+    q, v, ctrl = random_states(m, n, rng)
+    pre = oracle_rollout(m, q, v, ctrl, 60)
+    sim = hs.BatchSim(m, n)
+    assert sim.is_persistent()
+    sim.set_debug(True)
+    sim.set_warmstart(np.array([s.qacc_warmstart for s in pre]))
+    sim.set_state(np.zeros(n), np.array([s.qpos for s in pre]), np.array([s.qvel for s in pre]))
+    obs = sim.step(ctrl, 1)[0]
+    ncon = sim.get_field(hs.F_NCON)
+    assert not sim.bad_state()[0].any() and int((ncon > 0).sum()) > n // 2
+    unexplained = []
+    for e in range(n):
+        o = pre[e]
+        o.step()
+        dq = np.abs(obs[e, :m.nq] - o.qpos).max()
+        dv = (np.abs(obs[e, m.nq:] - o.qvel) / (1 + np.abs(o.qvel))).max()
+        if not (dq < 5e-6 and dv < 1e-4) and int(ncon[e]) == o.ncon:
+            unexplained.append((e, dq, dv))
+    assert not unexplained, unexplained
+    outs = []
+    for persistent in (True, False):
+        sim.set_persistent(persistent)
+        sim.set_warmstart(np.zeros((n, m.nv)))
+        sim.set_state(np.zeros(n), q, np.zeros_like(v))
+        outs.append(sim.step(ctrl, 60)[0])
+    err = np.abs(outs[0] - outs[1]).max(axis=1)
+    assert np.median(err) < 1e-5 and np.percentile(err, 90) < 1e-3, err
+    sim.close()
+
+
 def test_group_sums_are_identical_in_every_lane(models):
     """Regression (round 2): a state of cfg4 (tests/golden/cfg4_lane_uniformity_state.npz, found by replaying the bench) in which
     the lanes of one env disagreed in the last bit of a group sum - the compiler had contracted the product in gsum's argument
