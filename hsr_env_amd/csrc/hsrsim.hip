@@ -176,6 +176,7 @@ struct hsr_batch {
     bool persist = false;          // whole env-step in one persistent kernel (k_env_step_mf); HSR_PERSIST=0 disables
     bool persist_ok = false;       // the model fits the persistent kernel (lane maps, LDS, kinematic structure): set once at creation
     bool use_graph = true, profiling = false, debug_store = false;
+    bool persist_tg = false;       // persistent kernel instance that reads its pair / geom tables from global memory (LDS budget)
     int test_hooks = 0;            // hsr_batch_set_debug bits 1.. : force rarely taken solver branches (tests only)
     bool schedule = true;          // re-pack the envs over the waves of the persistent kernel before every launch (HSR_SCHEDULE=0 / hsr_batch_set_schedule turn it off)
     int *d_slot_env = nullptr;
@@ -186,9 +187,25 @@ struct hsr_batch {
     std::vector<hipEvent_t> kev;
 };
 
+// global copies of the two constant LDS tables of the persistent kernel (same packing: kin2.h)
+__global__ void k_build_tables(DevModel m, DevState s) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < m.ngeom) geom_consts_store(m.geom_rec + 32 * i, s.geom_c + 8 * i);
+    if (i < ((m.npair_pad + 7) & ~7)) {
+        unsigned pk = 0;
+        if (i < m.npair) {
+            const float4 a = reinterpret_cast<const float4 *>(m.pair_geo)[2 * i], b = reinterpret_cast<const float4 *>(m.pair_geo)[2 * i + 1];
+            const int code = (int)a.x;
+            pk = pair_pack(code & 255, (int)a.y, (int)b.x, (code >> 8) ? a.w : a.z + a.w);
+        }
+        s.pair_pack[i] = pk;
+    }
+}
+
 // the persistent kernel instantiations: (lanes per env, compile-time bound on nv)
 typedef void (*persist_fn)(const DevModel *, DevState, int, int, float, int);
-static persist_fn persist_kernel(int group, int nv, int ndense) {
+static persist_fn persist_kernel(int group, int nv, int ndense, bool tg = false) {
+    if (tg) return (group == 16 && nv == 13) ? k_env_step_mf<16, 13, true, -1, true> : nullptr;          // the cupboard scene
     // the compiled reference configurations get instances with nv and ndense at compile time; anything else the generic ones
     if (group == 16) {
         if (nv == 2 && ndense == 0) return k_env_step_mf<16, 2, true, 0>;            // cfg1: two orthogonal slides
@@ -521,6 +538,8 @@ static int batch_init(hsr_batch *b, const hsr_model *m, int n_envs) {
     DA(kin_aos, s.kstride)
     DA(con, 8 * d.nslot) DA(ncon_pair, d.npair_pad) DA(sepax, 4 * std::max(d.npair, 1)) DA(pair_list, std::max(d.npair, 1))
     if ((rc = dalloc(b, &s.pair_count, (size_t)d.npair_pad))) return rc;
+    if ((rc = dalloc(b, &s.pair_pack, (size_t)((d.npair_pad + 7) & ~7)))) return rc;
+    if ((rc = dalloc(b, &s.geom_c, (size_t)8 * std::max(d.ngeom, 1)))) return rc;
     DA(M, d.nM) DA(qacc, d.nv) DA(qacc_smooth, d.nv) DA(qfrc_smooth, d.nv) DA(qfrc_constraint, d.nv)
     DA(ncon, 1) DA(nefc, 1) DA(niter, 1)
 #undef DA
@@ -550,8 +569,20 @@ static int batch_init(hsr_batch *b, const hsr_model *m, int n_envs) {
         }
     }
     {
-        const int total = b->group == 16 ? PersistLayout<16>(d.njmax, b->ds.kstride, d.npair_pad, d.nlink, d.ngeom, d.nstatic_geom).total : PersistLayout<32>(d.njmax, b->ds.kstride, d.npair_pad, d.nlink, d.ngeom, d.nstatic_geom).total;
-        b->persist_lds_bytes = (size_t)total * sizeof(float);
+        auto lds_total = [&](bool tg) { return (size_t)sizeof(float) * (b->group == 16 ? PersistLayout<16>(d.njmax, b->ds.kstride, d.npair_pad, d.nlink, d.ngeom, d.nstatic_geom, tg).total
+                                                                                            : PersistLayout<32>(d.njmax, b->ds.kstride, d.npair_pad, d.nlink, d.ngeom, d.nstatic_geom, tg).total); };
+        b->persist_lds_bytes = lds_total(false);
+        {   // a model whose tables cost the eighth workgroup per CU (160 KB / 8 = 20480 B each, static LDS included) reads them from global memory
+            hipFuncAttributes fa;
+            persist_fn f0 = persist_kernel(b->group, d.nv, d.ndense, false), f1 = persist_kernel(b->group, d.nv, d.ndense, true);
+            if (f1 && hipFuncGetAttributes(&fa, (const void *)f0) == hipSuccess && b->persist_lds_bytes + fa.sharedSizeBytes > 20480
+                && hipFuncGetAttributes(&fa, (const void *)f1) == hipSuccess && lds_total(true) + fa.sharedSizeBytes <= 20480) {
+                b->persist_tg = true;
+                b->persist_lds_bytes = lds_total(true);
+            }
+            const char *tg = getenv("HSR_TABLES_GLOBAL");                    // diagnostic: 0 keeps the tables in LDS
+            if (tg && strcmp(tg, "0") == 0 && b->persist_tg) { b->persist_tg = false; b->persist_lds_bytes = lds_total(false); }
+        }
         // what the persistent kernel's lane maps and kinematics assume (kin2.h, persist.h); a model outside it runs the per-substep chain
         bool ok = d.nq <= b->group && d.nv <= b->group && d.nlink <= b->group && d.nlink <= NLMAX && d.ngeom <= 64 && d.npair < (1 << 14) && d.maxdepth <= 9;
         {
@@ -583,13 +614,13 @@ static int batch_init(hsr_batch *b, const hsr_model *m, int n_envs) {
         const char *pe = getenv("HSR_PERSIST");
         b->persist = ok && !(pe && strcmp(pe, "0") == 0);
         if (ok && b->persist_lds_bytes > 48 * 1024)
-            HIPCHK(hipFuncSetAttribute((const void *)persist_kernel(b->group, d.nv, d.ndense), hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->persist_lds_bytes));
+            HIPCHK(hipFuncSetAttribute((const void *)persist_kernel(b->group, d.nv, d.ndense, b->persist_tg), hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->persist_lds_bytes));
     }
     if (getenv("HSR_DEBUG") && b->persist_ok) {
         int pb = -1;
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&pb, persist_kernel(b->group, d.nv, d.ndense), 64, b->persist_lds_bytes);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&pb, persist_kernel(b->group, d.nv, d.ndense, b->persist_tg), 64, b->persist_lds_bytes);
         hipFuncAttributes fb;
-        if (hipFuncGetAttributes(&fb, (const void *)persist_kernel(b->group, d.nv, d.ndense)) == hipSuccess)
+        if (hipFuncGetAttributes(&fb, (const void *)persist_kernel(b->group, d.nv, d.ndense, b->persist_tg)) == hipSuccess)
             fprintf(stderr, "[hsrsim] k_env_step_mf<%d>: regs %d, static LDS %zu, dyn LDS %zu, scratch %zu -> %d workgroups per CU\n", b->group, fb.numRegs, fb.sharedSizeBytes, b->persist_lds_bytes, fb.localSizeBytes, pb);
     }
     {
@@ -608,6 +639,7 @@ static int batch_init(hsr_batch *b, const hsr_model *m, int n_envs) {
     if ((rc = dalloc(b, &d_q0, (size_t)d.nq))) return rc;
     HIPCHK(hipMemcpy(d_q0, m->qpos0.data(), d.nq * sizeof(float), hipMemcpyHostToDevice));
     b->d_qpos0 = d_q0;
+    hipLaunchKernelGGL(k_build_tables, grid1((size_t)std::max(d.ngeom, (d.npair_pad + 7) & ~7)), dim3(256), 0, b->stream, b->dm, b->ds);
     hipLaunchKernelGGL(k_reset, grid1(N), dim3(256), 0, b->stream, b->dm, b->ds, (const uint8_t *)nullptr, (const float *)nullptr, (const float *)d_q0, (const float *)nullptr);
     HIPCHK(hipStreamSynchronize(b->stream));
     return HSR_OK;
@@ -849,7 +881,7 @@ extern "C" int hsr_batch_step_dev(hsr_batch *b, const float *d_ctrl, int n_subst
         if (sched) hipLaunchKernelGGL(k_schedule, dim3((N + SCHED_CHUNK - 1) / SCHED_CHUNK), dim3(1024), 0, st, b->ds, epb, b->d_slot_env);
         DevState dsl = b->ds;
         dsl.slot_env = sched ? b->d_slot_env : nullptr;
-        hipLaunchKernelGGL(persist_kernel(b->group, b->dm.nv, b->dm.ndense), dim3((N + epb - 1) / epb), dim3(64), b->persist_lds_bytes, st, (const DevModel *)b->d_dm, dsl, n_substeps, goal_body, geofence, (b->debug_store ? 1 : 0) | b->test_hooks);
+        hipLaunchKernelGGL(persist_kernel(b->group, b->dm.nv, b->dm.ndense, b->persist_tg), dim3((N + epb - 1) / epb), dim3(64), b->persist_lds_bytes, st, (const DevModel *)b->d_dm, dsl, n_substeps, goal_body, geofence, (b->debug_store ? 1 : 0) | b->test_hooks);
         if (b->profiling) { hipEvent_t ev; hipEventCreate(&ev); hipEventRecord(ev, st); b->kev.push_back(ev); }   // slots 0,1 empty; slot 2 = the persistent kernel
     } else if (b->use_graph && !b->profiling && n_substeps > 0) {
         GraphKey key{n_substeps, goal_body, geofence};

@@ -56,6 +56,8 @@ struct DevState {
     int *pair_count, *pair_list;   // per-pair work lists of the narrowphase: count[npair_pad], list[npair][N] env ids
     float *sepax;             // [4 npair][N] per (pair, env) of the MPR pairs: cached separating direction (0 = none), then the separation left along it
     int npair_sep;            // rows of sepax / 4
+    unsigned *pair_pack;      // [npair padded to 8] packed sphere-cull records and [ngeom][8] narrowphase constants: global copies of the two
+    float *geom_c;            // LDS tables of the persistent kernel, read instead of them by its TG instances (models whose LDS would not fit 8 workgroups per CU)
     // dynamics / solver outputs kept for introspection
     float *M, *qacc, *qacc_smooth, *qfrc_smooth, *qfrc_constraint;
     int *ncon, *nefc, *niter;

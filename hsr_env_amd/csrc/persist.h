@@ -20,7 +20,8 @@
 
 template <int G> struct PersistLayout {
     int R, MS, oRows, oCnt, oB, envf, oPoly, oKin, oPair, oGeomC, oGeomS, oLinkTab, total;
-    __host__ __device__ PersistLayout(int rows, int kstride, int npair_pad, int nlink, int ngeom, int nstatic) {
+    // tables_global: the packed pair records and the geom constants stay in global memory (DevState::pair_pack / geom_c)
+    __host__ __device__ PersistLayout(int rows, int kstride, int npair_pad, int nlink, int ngeom, int nstatic, bool tables_global = false) {
         R = rows; MS = G + 1;
         int a = 5 * R > kstride ? 5 * R : kstride;                            // row scalars / kin record
         oRows = 0; oCnt = (a + 3) & ~3;                                       // pair counts survive phases A-D next to the kin record
@@ -34,8 +35,8 @@ template <int G> struct PersistLayout {
         oPoly = envf * (64 / G);                                               // box-box polygon scratch: 24 floats per 8-lane sub-group
         oKin = oPoly + 4 * 48;                                                 // per-link kinematic constants (kin2.h), shared by the envs of the workgroup
         oPair = oKin + KIN2_FLOATS * nlink;                                     // packed sphere-cull record per candidate pair (one dword), rows of 8
-        oGeomC = oPair + ((npair_pad + 7) & ~7);                                // narrowphase constants of every geom (8 floats each)
-        oGeomS = oGeomC + 8 * ngeom;                                            // world placements of the static geoms (16 floats each)
+        oGeomC = oPair + (tables_global ? 0 : ((npair_pad + 7) & ~7));          // narrowphase constants of every geom (8 floats each)
+        oGeomS = oGeomC + (tables_global ? 0 : 8 * ngeom);                                            // world placements of the static geoms (16 floats each)
         oLinkTab = oGeomS + 16 * nstatic;                                       // chain dof mask and mass of every link
         total = (oLinkTab + 2 * nlink + 3) & ~3;
     }
@@ -44,14 +45,15 @@ template <int G> struct PersistLayout {
 // NVT: compile-time bound on nv (nv <= NVT <= G); the matrix loops of the solver run to NVT instead of G
 // EXACT: nv == NVT, known at compile time (the `j < nv` guards of the unrolled matrix loops fold away)
 // NDT (EXACT only, else -1): ndense at compile time - the dofs from NDT on never couple to another dof in M (free bodies)
-template <int G, int NVT, bool EXACT, int NDT = -1>
+// TG: pair records / geom constants read from global memory instead of LDS (for models with many pairs: 8 workgroups per CU)
+template <int G, int NVT, bool EXACT, int NDT = -1, bool TG = false>
 __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restrict__ mp, DevState s, int n_substeps, int goal_body, float geofence, int flags) {
     // the ~90 model fields stay in (constant-cached) memory and are read where they are used, instead of sitting in - and
     // spilling from - SGPRs for the whole launch
     const DevModel &m = *mp;
     extern __shared__ __align__(16) float lds[];
     constexpr int EPB = 64 / G, NK = NVT, NDK = EXACT ? NDT : -1;
-    const PersistLayout<G> L(m.njmax, s.kstride, m.npair_pad, m.nlink, m.ngeom, m.nstatic_geom);
+    const PersistLayout<G> L(m.njmax, s.kstride, m.npair_pad, m.nlink, m.ngeom, m.nstatic_geom, TG);
     const int tid0 = threadIdx.x;
     const int N = s.N, nv = EXACT ? NVT : m.nv, nq = m.nq, R = L.R, MS = L.MS;
     const int mode = 1, debug = 0;
@@ -98,7 +100,7 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
     if (tid0 < m.nlink) kin2_store(m, tid0, lds + L.oKin + KIN2_FLOATS * tid0);
     // geom cache: constants of every geom, placements of the static ones (world link: identity pose)
     for (int gi = tid0; gi < m.ngeom; gi += 64) {
-        geom_consts_store(m.geom_rec + 32 * gi, lds + L.oGeomC + 8 * gi);
+        if constexpr (!TG) geom_consts_store(m.geom_rec + 32 * gi, lds + L.oGeomC + 8 * gi);
         if (gi < m.nstatic_geom) {
             m3 I3;
 #pragma unroll
@@ -107,7 +109,7 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
         }
     }
     // sphere-cull records of the candidate pairs (kin2.h: pair_pack)
-    for (int p = tid0; p < ((m.npair_pad + 7) & ~7); p += 64) {
+    if constexpr (!TG) for (int p = tid0; p < ((m.npair_pad + 7) & ~7); p += 64) {
         unsigned pk = 0;
         if (p < m.npair) {
             const float4 a = reinterpret_cast<const float4 *>(m.pair_geo)[2 * p], b = reinterpret_cast<const float4 *>(m.pair_geo)[2 * p + 1];
@@ -233,7 +235,8 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
             const int oGw = (int)(gw - E);
             // placement of geom gi: static ones in the shared table, moving ones in this env's cache
             auto gaddr = [&](int gi, const float *Ei) -> const float * { return gi < nstat ? lds + L.oGeomS + 16 * gi : Ei + oGw + 16 * (gi - nstat); };
-            const float *gcc = lds + L.oGeomC;
+            const float *gcc;
+            if constexpr (TG) gcc = s.geom_c; else gcc = lds + L.oGeomC;
             if (valid) {
                 for (int gm = c; gm < nmov; gm += G) {
                     const GeomPlaceC k2 = gm < G ? gpc : geom_place_consts(m.geom_rec + 32 * (nstat + gm));
@@ -251,7 +254,8 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
             wave_sync();
             PHASE_K(30);
             const float4 *pg4 = reinterpret_cast<const float4 *>(m.pair_geo);
-            const unsigned *sPair = reinterpret_cast<const unsigned *>(lds + L.oPair);
+            const unsigned *sPair;
+            if constexpr (TG) sPair = s.pair_pack; else sPair = reinterpret_cast<const unsigned *>(lds + L.oPair);
             unsigned short *sCand = reinterpret_cast<unsigned short *>(poly);      // 128 entries in the box-box polygon scratch (dead during the culls)
             int ncand = 0, nitems = 0;                             // wave-uniform
             int nit_env[EPB];                                      // items per env (wave-uniform): an env keeps at most 64, whatever its neighbours do

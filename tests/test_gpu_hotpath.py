@@ -211,6 +211,25 @@ def test_rarely_taken_solver_branches(models, cfg, hook):
     sim.close()
 
 
+def test_pair_tables_in_global_memory_change_nothing(models, monkeypatch):
+    """The cupboard scene (274 candidate pairs) would need 22.4 KB of LDS per workgroup - 7 workgroups per CU, a second round of 256
+    workgroups at 8192 envs; its kernel instance reads the packed pair records and geom constants from global memory instead
+    (8 per CU).  Same values, same arithmetic: bit-identical with the tables in LDS (HSR_TABLES_GLOBAL=0)."""
+    m = models["cupboard"]
+    n = 128
+    rng = np.random.default_rng(8)
+    q, v, ctrl = random_states(m, n, rng)
+    outs = []
+    for tg in ("1", "0"):
+        monkeypatch.setenv("HSR_TABLES_GLOBAL", tg)
+        sim = hs.BatchSim(m, n)
+        sim.set_state(np.zeros(n), q, v)
+        outs.append([sim.step(ctrl, 50)[0].copy() for _ in range(2)])
+        sim.close()
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b)
+
+
 @pytest.mark.parametrize("cfg", ["nv11", "nv23"])
 def test_generic_instances_of_the_persistent_kernel(models, cfg):
     """The reference configurations run kernel instances with nv and ndense at compile time; any other model gets the generic
