@@ -102,23 +102,51 @@ def cpu_baseline(m, q0, goal, ctrl, cores):
 
 def self_launch(args):
     """`python bench.py --gpus N` without a launcher: start N ranks of this script (env:// rendezvous on 127.0.0.1), relay rank
-    0's output, fail if any rank fails.  Runs before torch / HIP are touched - the parent process never initialises the GPU."""
+    0's output, fail if any rank fails.  Runs before torch / HIP are touched - the parent process never initialises the GPU.
+    The ranks are polled together: the first one that fails takes the others down with it (a rank whose peer died would sit in the
+    rendezvous until its timeout, holding its GPU), and none survives the parent."""
     import socket
     import subprocess
+    import tempfile
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     procs = []
-    for r in range(args.gpus):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out, _ = procs[0].communicate()
-    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out)
-    sys.stdout.flush()
-    return next((c for c in codes if c), 0)
+    out0 = tempfile.TemporaryFile(mode="w+")
+    try:
+        for r in range(args.gpus):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                          stdout=out0 if r == 0 else subprocess.DEVNULL, text=True))
+        worst = 0
+        live = list(procs)
+        while live:
+            for p in list(live):
+                rc = p.poll()
+                if rc is None:
+                    continue
+                live.remove(p)
+                if rc != 0 and worst == 0:
+                    worst = rc
+                    for q in live:
+                        q.terminate()
+            if live:
+                time.sleep(0.05)
+        out0.seek(0)
+        sys.stdout.write(out0.read())
+        sys.stdout.flush()
+        return worst
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        for p in procs:
+            try:
+                p.wait(timeout=10)
+            except Exception:
+                pass
+        out0.close()
 
 
 def main():
@@ -136,10 +164,16 @@ def main():
                          "goes through gloo on host copies (RCCL refuses two ranks on one device); the number it prints is not a result")
     ap.add_argument("--launch-check", action="store_true", help="print this rank's rendezvous environment and exit (no GPU touched): "
                     "exercises the self-launcher of --gpus N on a machine without GPUs")
+    ap.add_argument("--fail-rank", type=int, default=-1, help="with --launch-check: this rank exits with code 3 at once and the others "
+                    "wait (as a rank does whose peer never reaches the rendezvous) - the launcher has to take them down")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(args))
     if args.launch_check:
+        if args.fail_rank >= 0:
+            if int(os.environ.get("RANK", 0)) == args.fail_rank:
+                raise SystemExit(3)
+            time.sleep(120)
         print(json.dumps({k: os.environ.get(k) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}))
         return
 
@@ -159,16 +193,13 @@ def main():
     dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
-        if args.rehearse_on_one_gpu:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=dev)
+        hdist.init_process_group("gloo" if args.rehearse_on_one_gpu else "nccl", dev)
 
     m = load_config(args.config)
     n = args.envs_per_gpu
     offset = rank * n
     K, W = args.steps, args.warmup
-    total = K + W + 1                       # +1 profiled env-step after the timed region
+    total = K + W
     q0, goal = sample_inputs(m, n, 0, offset)
     rng = np.random.Generator(np.random.Philox(key=[1, offset]))
     lo, hi = m.act_ctrlrange[:, 0].astype(np.float32), m.act_ctrlrange[:, 1].astype(np.float32)
@@ -189,30 +220,22 @@ def main():
     nobs = m.nq + m.nv
     d_obs = torch.empty((n, nobs), dtype=torch.float32, device=dev)
     d_rew = torch.empty(n, dtype=torch.float32, device=dev)
-    d_done = torch.empty(n, dtype=torch.uint8, device=dev)
-    d_ns = torch.empty(n, dtype=torch.int32, device=dev)
-    d_pack = torch.empty((n, nobs + 2), dtype=torch.float32, device=dev)
-    d_all = torch.empty((world * n, nobs + 2), dtype=torch.float32, device=dev) if world > 1 else None
+    # done / nsteps of every env-step are kept (5 bytes per env and step) and summed after the timed region: no reduction kernels in it
+    d_done = torch.empty((total, n), dtype=torch.uint8, device=dev)
+    d_ns = torch.empty((total, n), dtype=torch.int32, device=dev)
     bid = m.body_id(m.block_body()) if m.block_body() else -1
-    substeps_done = torch.zeros((), dtype=torch.int64, device=dev)
-    dones = torch.zeros((), dtype=torch.int64, device=dev)
 
-    # torch ops (reductions, packing, the RCCL all-gather) are enqueued on the batch's own stream
+    # torch ops (packing, the RCCL all-gather) are enqueued on the batch's own stream
     ext = torch.cuda.ExternalStream(sim.stream_ptr(), device=dev)
     torch.cuda.set_stream(ext)
+    gather = hdist.StepGather(n, nobs, world, dev) if world > 1 else None
 
     def env_step(k):
         sim.step_dev(d_ctrl[k].data_ptr(), STEPS_PER_ACTION, bid, GEOFENCE, d_obs.data_ptr(), d_rew.data_ptr(),
-                     d_done.data_ptr(), d_ns.data_ptr())
+                     d_done[k].data_ptr(), d_ns[k].data_ptr())
+        if gather is not None:
+            gather(d_obs, d_rew, d_done[k])                              # obs / reward / done of every rank's shard
         sim.reset_dev(None, d_rq[k].data_ptr(), d_rg[k].data_ptr())     # `if done: env.reset()`
-        if world > 1:
-            d_pack[:, :nobs] = d_obs; d_pack[:, nobs] = d_rew; d_pack[:, nobs + 1] = d_done
-            if args.rehearse_on_one_gpu:
-                h_all = torch.empty(d_all.shape, dtype=d_all.dtype)
-                dist.all_gather_into_tensor(h_all, d_pack.cpu())
-                d_all.copy_(h_all)
-            else:
-                dist.all_gather_into_tensor(d_all, d_pack)
 
     def barrier():
         if world > 1:
@@ -221,44 +244,52 @@ def main():
 
     for k in range(W):
         env_step(k)
-        substeps_done += d_ns.sum()     # same ops as the timed loop (torch loads its reduction kernels on first use)
-        dones += d_done.sum()
-    if W == 0:
-        substeps_done += d_ns.sum(); dones += d_done.sum()
     barrier()
-    substeps_done.zero_(); dones.zero_()
+    sim.cap_counts()                        # clears the counters: the cap statistics below cover the timed steps only
+    sim.set_profiling(2)                    # an event pair around every launch of the persistent kernel, no synchronisation
     barrier()
     t0 = time.perf_counter()
     for k in range(W, W + K):
         env_step(k)
-        substeps_done += d_ns.sum()     # on torch's stream; ordered by the device-wide sync below
-        dones += d_done.sum()
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cpu" if args.rehearse_on_one_gpu else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    substeps_done = int(d_ns[W:W + K].sum().item())
+    dones = int(d_done[W:W + K].sum().item())
 
-    # per-kernel average launch duration (HIP events on the batch stream), one extra env-step
-    sim.set_profiling(True)
-    sim.step_dev(d_ctrl[W + K].data_ptr(), STEPS_PER_ACTION, bid, GEOFENCE, d_obs.data_ptr(), d_rew.data_ptr(), d_done.data_ptr(), d_ns.data_ptr())
-    sim.sync()
-    tot_ms, k_ms, k_n = sim.last_timing()
-    sim.set_profiling(False)
+    # launch durations of the dominant kernel over the timed region (HIP events on the batch stream, one pair per launch)
     if persistent:
         # one launch = one env-step of every env (kinematics + collision + solve + integrate, 300 substeps in-kernel)
+        k_all = sim.kernel_times()
+        sim.set_profiling(False)
+        assert len(k_all) == K, (len(k_all), K)
         names = ["-", "-", "k_env_step_mf"]
         dom = 2
         units_per_launch = STEPS_PER_ACTION
+        avg_us = 1e3 * float(k_all.mean())
+        k_ms = [0.0, 0.0, float(k_all.mean())]; k_n = [0, 0, 1]
+        kernel_stats = {"kernel_ms_mean": float(k_all.mean()), "kernel_ms_min": float(k_all.min()), "kernel_ms_max": float(k_all.max()),
+                        "launches_timed": int(len(k_all)), "outside_kernel_ms": 1e3 * dt / K - float(k_all.mean())}
     else:
+        # per-substep chain: one extra profiled env-step (its event log synchronises, so it stays outside the timed region)
+        sim.set_profiling(True)
+        sim.step_dev(d_ctrl[W + K - 1].data_ptr(), STEPS_PER_ACTION, bid, GEOFENCE, d_obs.data_ptr(), d_rew.data_ptr(), d_done[0].data_ptr(), d_ns[0].data_ptr())
+        sim.sync()
+        tot_ms, k_ms, k_n = sim.last_timing()
+        sim.set_profiling(False)
         names = ["k_kinematics", "k_cull+k_narrow", "k_solve_mf"]
         dom = int(np.argmax(k_ms))
         units_per_launch = 1
-    avg_us = 1e3 * k_ms[dom] / max(k_n[dom], 1)
-    # algorithmic bytes: fp32 state stream per substep per env = 4*(2nq+2nv+nu+3) (SURVEY.md 8d / BASELINE.md 3)
+        avg_us = 1e3 * k_ms[dom] / max(k_n[dom], 1)
+        kernel_stats = {}
+    mean_substeps = substeps_done / (n * K)
+    # algorithmic bytes: fp32 state stream per substep per env = 4*(2nq+2nv+nu+3) (SURVEY.md 8d / BASELINE.md 3), times the
+    # substeps a launch really ran (early exits shorten it), plus the obs / reward / done write of the persistent launch
     bytes_per_substep_env = 4 * (2 * m.nq + 2 * m.nv + m.nu + 3)
-    bytes_per_launch = bytes_per_substep_env * n * units_per_launch + (4 * (m.nq + m.nv) + 5) * n * (1 if persistent else 0)
+    bytes_per_launch = bytes_per_substep_env * n * (mean_substeps if persistent else 1) + (4 * (m.nq + m.nv) + 5) * n * (1 if persistent else 0)
     achieved = bytes_per_launch / (avg_us * 1e-6) / 1e9
     traffic = None
     pmc = ROOT / "profiles" / "pmc_summary.json"
@@ -268,7 +299,6 @@ def main():
         except Exception:
             traffic = None
     value = world * n * K / dt
-    mean_substeps = float(substeps_done.item()) / (n * K)
     bad, any_bad = sim.bad_state()
     cap_con, cap_row, cap_item, cap_total = sim.cap_counts()
     nblocks = len(m.free_joint_qadrs())
@@ -290,6 +320,16 @@ def main():
     except Exception:
         valu = None
 
+    # lifetimes of the workgroups of one launch (the launch ends with its slowest workgroup): measured with the diagnostic build
+    # libhsrsim_life.so by tools/block_life.py and committed with the round's profiles
+    lifetimes = None
+    try:
+        lf = ROOT / "profiles" / "block_life.json"
+        if lf.exists():
+            lifetimes = json.loads(lf.read_text()).get(args.config)
+    except Exception:
+        lifetimes = None
+
     out = {
         "metric": f"env-steps/sec (whole node), HSR+{nblocks}-block, steps_per_action={STEPS_PER_ACTION}, {n} envs",
         "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
@@ -298,7 +338,7 @@ def main():
         "config": {"workload": f"{baseline_cfg}: {args.config}, {dofs} + {nblocks} block(s), {n} envs per GPU x {world} GPU(s), "
                                f"steps_per_action={STEPS_PER_ACTION}, geofence={GEOFENCE}, ctrl~U(ctrlrange) per env-step, done envs reset",
                    "envs_per_gpu": n, "global_envs": world * n, "substeps_per_env_step": STEPS_PER_ACTION,
-                   "mean_substeps_executed": mean_substeps, "done_fraction": float(dones.item()) / (n * K),
+                   "mean_substeps_executed": mean_substeps, "done_fraction": dones / (n * K),
                    "parallelism": f"env-shard x{world}" + (f" + all-gather(obs,reward,done) over {'gloo (rehearsal)' if args.rehearse_on_one_gpu else 'RCCL'}, {dist.get_world_size()} ranks" if world > 1 else ""),
                    "cap_hits": {"contacts_beyond_nconmax": cap_con / max(cap_total, 1), "rows_beyond_njmax": cap_row / max(cap_total, 1),
                                 "items_beyond_64_per_env": cap_item / max(cap_total, 1), "env_substeps": cap_total,
@@ -307,7 +347,8 @@ def main():
                    "bad_envs": int(bad.sum())},
         "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                     "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_us": avg_us,
+                     "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_us": avg_us, **kernel_stats,
+                     "workgroup_lifetimes": lifetimes,
                      "valu": valu,
                      "kernel_ms_per_env_step": {nm: ms for nm, ms in zip(names, k_ms) if nm != "-"},
                      "launches_per_env_step": {nm: k for nm, k in zip(names, k_n) if nm != "-"},

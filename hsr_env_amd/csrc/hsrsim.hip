@@ -98,21 +98,77 @@ static std::vector<std::pair<int, int>> json_pair_list(const std::string &js, si
 extern "C" int hsr_model_load(const void *blob, size_t len, hsr_model **out) {
     if (!blob || !out) return fail(HSR_EINVAL, "null argument");
     if (len < 16 || memcmp(blob, "HSRM0001", 8) != 0) return fail(HSR_EBLOB, "not an HSRM0001 model blob");
+    // the blob is untrusted input (hsr/mujoco_env.py:30-31: a bad model file is an IOError, never a crash): every length and offset
+    // is checked against `len` before it is used
+    const uint8_t *in = (const uint8_t *)blob;
+    uint32_t n;
+    memcpy(&n, in + 8, 4);
+    if (n > 4096 || 16 + (uint64_t)n * sizeof(BlobEntry) + 8 > len) return fail(HSR_EBLOB, "truncated model blob (entry table)");
+    uint64_t jl;
+    memcpy(&jl, in + 16 + (size_t)n * sizeof(BlobEntry), 8);
+    const uint64_t data_off = 16 + (uint64_t)n * sizeof(BlobEntry) + 8;
+    if (jl > len - data_off || (jl & 7) != 0) return fail(HSR_EBLOB, "truncated model blob (names / meta)");
+    const uint64_t data_len = len - data_off - jl;
+    {
+        const BlobEntry *ent0 = (const BlobEntry *)(in + 16);
+        for (uint32_t i = 0; i < n; i++) {
+            BlobEntry e;
+            memcpy(&e, ent0 + i, sizeof e);
+            if (e.off > data_len || e.nbytes > data_len - e.off) return fail(HSR_EBLOB, "model blob entry out of bounds");
+            if ((e.off & 7) != 0) return fail(HSR_EBLOB, "model blob entry misaligned");
+        }
+    }
     hsr_model *m = new hsr_model();
-    m->raw.assign((const uint8_t *)blob, (const uint8_t *)blob + len);
+    m->raw.assign(in, in + len);
     const uint8_t *raw = m->raw.data();
-    uint32_t n = *(const uint32_t *)(raw + 8);
     const BlobEntry *ent = (const BlobEntry *)(raw + 16);
     const uint8_t *p = raw + 16 + (size_t)n * sizeof(BlobEntry);
-    uint64_t jl = *(const uint64_t *)p;
     m->json.assign((const char *)p + 8, (size_t)jl);
     m->data = p + 8 + jl;
     for (uint32_t i = 0; i < n; i++) m->entries[std::string(ent[i].name, strnlen(ent[i].name, 32))] = &ent[i];
-    const int *sz = m->i32("sizes");
-    const double *op = m->f64("opt");
-    if (!sz || !op) { delete m; return fail(HSR_EBLOB, "blob lacks sizes/opt"); }
+    size_t nsz = 0, nop = 0;
+    const int *sz = m->i32("sizes", &nsz);
+    const double *op = m->f64("opt", &nop);
+    if (!sz || !op || nsz < 16 || nop < 16) { delete m; return fail(HSR_EBLOB, "blob lacks sizes/opt"); }
     memcpy(m->sizes, sz, sizeof m->sizes);
     memcpy(m->opt, op, sizeof m->opt);
+    for (int i = 0; i < 16; i++) if (m->sizes[i] < 0 || m->sizes[i] > (1 << 20)) { delete m; return fail(HSR_EBLOB, "blob sizes out of range"); }
+    {   // every table the host code and the kernels index by a model size must be at least that long, and every index table
+        // must point inside the table it indexes: a corrupted file is refused here, not found by a kernel
+        const int nq = m->sizes[HSR_NQ], nv = m->sizes[HSR_NV], nu = m->sizes[HSR_NU], nl = m->sizes[HSR_NLINK], nb = m->sizes[HSR_NBODY],
+                  ng = m->sizes[HSR_NGEOM], np_ = m->sizes[HSR_NPAIR], nmv = m->sizes[HSR_NMESHVERT], nslot = m->sizes[HSR_NSLOT];
+        struct Need { const char *name; int dtype; long long count; };
+        const Need need[] = {
+            {"qpos0", 0, nq}, {"link_parent", 1, nl}, {"link_pos", 0, 3LL * nl}, {"link_quat", 0, 4LL * nl}, {"link_dofadr", 1, nl}, {"link_dofnum", 1, nl},
+            {"link_qposadr", 1, nl}, {"link_free", 1, nl}, {"link_mass", 0, nl}, {"link_com", 0, 3LL * nl}, {"link_inertia", 0, 6LL * nl}, {"link_dofmask", 1, nl},
+            {"dof_link", 1, nv}, {"dof_type", 1, nv}, {"dof_axis", 0, 3LL * nv}, {"dof_pos", 0, 3LL * nv}, {"dof_parent", 1, nv}, {"dof_damping", 0, nv},
+            {"dof_qposadr", 1, nv}, {"dof_invweight0", 0, nv}, {"dof_limited", 1, nv}, {"dof_range", 0, 2LL * nv}, {"dof_solref", 0, 2LL * nv}, {"dof_solimp", 0, 5LL * nv},
+            {"body_link", 1, nb}, {"body_pos", 0, 3LL * nb}, {"body_quat", 0, 4LL * nb}, {"body_mocap", 1, nb},
+            {"geom_type", 1, ng}, {"geom_link", 1, ng}, {"geom_pos", 0, 3LL * ng}, {"geom_quat", 0, 4LL * ng}, {"geom_size", 0, 3LL * ng}, {"geom_rbound", 0, ng},
+            {"geom_meshadr", 1, ng}, {"geom_meshnum", 1, ng}, {"geom_invweight", 0, 2LL * ng}, {"geom_aabb", 0, 6LL * ng}, {"mesh_vert", 0, 3LL * nmv},
+            {"pair_geom1", 1, np_}, {"pair_geom2", 1, np_}, {"pair_fn", 1, np_}, {"pair_condim", 1, np_}, {"pair_slot", 1, np_ + 1LL}, {"pair_friction", 0, 5LL * np_},
+            {"pair_solref", 0, 2LL * np_}, {"pair_solimp", 0, 5LL * np_},
+            {"act_dof", 1, nu}, {"act_gear", 0, nu}, {"act_kp", 0, nu}, {"act_ctrlrange", 0, 2LL * nu}, {"act_forcerange", 0, 2LL * nu}};
+        for (const Need &nd : need) {
+            auto it = m->entries.find(nd.name);
+            if (it == m->entries.end()) { delete m; return fail(HSR_EBLOB, "blob entry '%s' missing", nd.name); }
+            if ((int)it->second->dtype != nd.dtype || (long long)(it->second->nbytes / (nd.dtype == 0 ? 8 : 4)) < nd.count) { delete m; return fail(HSR_EBLOB, "blob entry '%s' shorter than the model sizes say", nd.name); }
+        }
+        auto in_range = [&](const char *name, int cnt, int lo, int hi) {       // all of the first cnt values in [lo, hi)
+            const int *v = m->i32(name);
+            for (int i = 0; i < cnt; i++) if (v[i] < lo || v[i] >= hi) return false;
+            return true;
+        };
+        bool ok = nl >= 1 && in_range("link_parent", nl, 0, nl) && in_range("dof_link", nv, 0, nl) && in_range("dof_parent", nv, -1, nv) && in_range("dof_qposadr", nv, 0, nq > 0 ? nq : 1)
+                  && in_range("body_link", nb, 0, nl) && in_range("geom_link", ng, 0, nl) && in_range("pair_geom1", np_, 0, ng) && in_range("pair_geom2", np_, 0, ng)
+                  && in_range("pair_fn", np_, 0, 4) && in_range("pair_slot", np_ + 1, 0, nslot + 1) && in_range("act_dof", nu, 0, nv > 0 ? nv : 1)
+                  && in_range("link_dofadr", nl, -1, nv + 1) && in_range("link_dofnum", nl, 0, nv + 1) && in_range("link_qposadr", nl, -1, nq + 1);
+        if (ok) {
+            const int *ma = m->i32("geom_meshadr"), *mn = m->i32("geom_meshnum"), *gt = m->i32("geom_type");
+            for (int g = 0; g < ng; g++) if (gt[g] == GEOM_MESH && (ma[g] < 0 || mn[g] < 0 || (long long)ma[g] + mn[g] > nmv)) ok = false;
+        }
+        if (!ok) { delete m; return fail(HSR_EBLOB, "blob index table out of range"); }
+    }
     size_t np = json_find_key(m->json, "names");
     if (np != std::string::npos) {
         size_t bp = json_find_key(m->json, "body", np), jp = json_find_key(m->json, "joint", np);
@@ -122,7 +178,9 @@ extern "C" int hsr_model_load(const void *blob, size_t len, hsr_model **out) {
     size_t qp = json_find_key(m->json, "joint_qposadr");
     if (qp != std::string::npos) m->joint_qposadr = json_pair_list(m->json, qp);
     const int nu = m->sizes[HSR_NU], nq = m->sizes[HSR_NQ];
-    const double *cr = m->f64("act_ctrlrange"), *q0 = m->f64("qpos0");
+    size_t ncr = 0, nq0 = 0;
+    const double *cr = m->f64("act_ctrlrange", &ncr), *q0 = m->f64("qpos0", &nq0);
+    if ((nu > 0 && (!cr || ncr < (size_t)nu * 2)) || (nq > 0 && (!q0 || nq0 < (size_t)nq))) { delete m; return fail(HSR_EBLOB, "blob lacks act_ctrlrange / qpos0"); }
     m->ctrlrange.resize((size_t)nu * 2);
     for (int i = 0; i < nu * 2; i++) m->ctrlrange[i] = (float)cr[i];
     m->qpos0.resize(nq);
@@ -185,6 +243,8 @@ struct hsr_batch {
     int last_launches[3] = {0, 0, 0};
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<hipEvent_t> kev;
+    bool kernel_log = false;       // hsr_batch_set_profiling(b, 2): an event pair around every launch of the persistent kernel, no synchronisation
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> klog;
 };
 
 // global copies of the two constant LDS tables of the persistent kernel (same packing: kin2.h)
@@ -203,7 +263,7 @@ __global__ void k_build_tables(DevModel m, DevState s) {
 }
 
 // the persistent kernel instantiations: (lanes per env, compile-time bound on nv)
-typedef void (*persist_fn)(const DevModel *, DevState, int, int, float, int);
+typedef void (*persist_fn)(const DevModel *, DevState, int, int, float, int, StepIO);
 static persist_fn persist_kernel(int group, int nv, int ndense, bool tg = false) {
     if (tg) return (group == 16 && nv == 13) ? k_env_step_mf<16, 13, true, -1, true> : nullptr;          // the cupboard scene
     // the compiled reference configurations get instances with nv and ndense at compile time; anything else the generic ones
@@ -305,11 +365,14 @@ __global__ void k_clear_done(DevState s) {
     int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e < s.N) s.done[e] = 0;
 }
-__global__ void k_reset(DevModel m, DevState s, const uint8_t *mask, const float *qpos0_env, const float *qpos0_model, const float *mocap) {
+// park: mask == NULL means "the envs whose done flag is set", and the envs that are not reset are left parked (done = 1) for the
+// forward pass of the reset ones (hsr_batch_reset_dev clears the flags after it)
+__global__ void k_reset(DevModel m, DevState s, const uint8_t *mask, const float *qpos0_env, const float *qpos0_model, const float *mocap, int park) {
     int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= s.N) return;
-    s.done[e] = 0;
-    if (mask && !mask[e]) return;
+    const bool sel = mask ? mask[e] != 0 : (park ? s.done[e] != 0 : true);
+    s.done[e] = (park && !sel) ? 1 : 0;
+    if (!sel) return;
     const int N = s.N;
     for (int i = 0; i < m.nq; i++) s.qpos[(size_t)i * N + e] = qpos0_env ? qpos0_env[(size_t)e * m.nq + i] : qpos0_model[i];
     for (int i = 0; i < m.nv; i++) { s.qvel[(size_t)i * N + e] = 0; s.warm[(size_t)i * N + e] = 0; s.qacc[(size_t)i * N + e] = 0; }
@@ -536,7 +599,7 @@ static int batch_init(hsr_batch *b, const hsr_model *m, int n_envs) {
     DA(xpos, 3 * d.nlink) DA(xmat, 9 * d.nlink) DA(lvel, 6 * d.nlink)
     s.kstride = (9 * d.nv + 15 * d.nlink + 15) & ~15;
     DA(kin_aos, s.kstride)
-    DA(con, 8 * d.nslot) DA(ncon_pair, d.npair_pad) DA(sepax, 4 * std::max(d.npair, 1)) DA(pair_list, std::max(d.npair, 1))
+    DA(con, 8 * d.nslot) DA(ncon_pair, d.npair_pad) DA(sepax, 4 * std::max(d.npair, 1)) DA(septick, std::max(d.npair, 1)) DA(tick, 1) DA(pair_list, std::max(d.npair, 1))
     if ((rc = dalloc(b, &s.pair_count, (size_t)d.npair_pad))) return rc;
     if ((rc = dalloc(b, &s.pair_pack, (size_t)((d.npair_pad + 7) & ~7)))) return rc;
     if ((rc = dalloc(b, &s.geom_c, (size_t)8 * std::max(d.ngeom, 1)))) return rc;
@@ -640,7 +703,7 @@ static int batch_init(hsr_batch *b, const hsr_model *m, int n_envs) {
     HIPCHK(hipMemcpy(d_q0, m->qpos0.data(), d.nq * sizeof(float), hipMemcpyHostToDevice));
     b->d_qpos0 = d_q0;
     hipLaunchKernelGGL(k_build_tables, grid1((size_t)std::max(d.ngeom, (d.npair_pad + 7) & ~7)), dim3(256), 0, b->stream, b->dm, b->ds);
-    hipLaunchKernelGGL(k_reset, grid1(N), dim3(256), 0, b->stream, b->dm, b->ds, (const uint8_t *)nullptr, (const float *)nullptr, (const float *)d_q0, (const float *)nullptr);
+    hipLaunchKernelGGL(k_reset, grid1(N), dim3(256), 0, b->stream, b->dm, b->ds, (const uint8_t *)nullptr, (const float *)nullptr, (const float *)d_q0, (const float *)nullptr, 0);
     HIPCHK(hipStreamSynchronize(b->stream));
     return HSR_OK;
 }
@@ -652,16 +715,33 @@ extern "C" void hsr_batch_destroy(hsr_batch *b) {
     for (auto &kv : b->graphs) hipGraphExecDestroy(kv.second);
     for (void *p : b->allocs) hipFree(p);
     for (hipEvent_t ev : b->kev) hipEventDestroy(ev);
+    for (auto &pr : b->klog) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
     if (b->ev0) hipEventDestroy(b->ev0);
     if (b->ev1) hipEventDestroy(b->ev1);
     if (b->stream) hipStreamDestroy(b->stream);
     delete b;
 }
-extern "C" int hsr_batch_size(const hsr_batch *b) { return b->N; }
-extern "C" void *hsr_batch_stream(const hsr_batch *b) { return (void *)b->stream; }
-extern "C" int hsr_batch_sync(hsr_batch *b) { HIPCHK(hipSetDevice(b->device)); HIPCHK(hipStreamSynchronize(b->stream)); return HSR_OK; }
-extern "C" int hsr_batch_set_profiling(hsr_batch *b, int on) { b->profiling = on != 0; return HSR_OK; }
-extern "C" int hsr_batch_set_graph(hsr_batch *b, int on) { b->use_graph = on != 0; return HSR_OK; }
+#define NULLCHK(b) do { if (!(b)) return fail(HSR_EINVAL, "null batch"); } while (0)
+extern "C" int hsr_batch_size(const hsr_batch *b) { NULLCHK(b); return b->N; }
+extern "C" void *hsr_batch_stream(const hsr_batch *b) { return b ? (void *)b->stream : nullptr; }
+extern "C" int hsr_batch_sync(hsr_batch *b) { NULLCHK(b); HIPCHK(hipSetDevice(b->device)); HIPCHK(hipStreamSynchronize(b->stream)); return HSR_OK; }
+extern "C" int hsr_batch_set_profiling(hsr_batch *b, int on) { NULLCHK(b); b->profiling = on == 1; b->kernel_log = on == 2; return HSR_OK; }
+// durations (ms) of the persistent-kernel launches logged since the last call (hsr_batch_set_profiling(b, 2)); synchronises the stream
+extern "C" int hsr_batch_kernel_times(hsr_batch *b, float *out_ms, int cap) {
+    NULLCHK(b);
+    HIPCHK(hipSetDevice(b->device));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    int n = 0;
+    for (auto &pr : b->klog) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess && out_ms && n < cap) out_ms[n] = ms;
+        n++;
+        hipEventDestroy(pr.first); hipEventDestroy(pr.second);
+    }
+    b->klog.clear();
+    return n;
+}
+extern "C" int hsr_batch_set_graph(hsr_batch *b, int on) { NULLCHK(b); b->use_graph = on != 0; return HSR_OK; }
 __global__ void k_clear_margins(DevState s) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < (size_t)s.npair_sep * s.N) s.sepax[(4 * (i / s.N) + 3) * s.N + i % s.N] = 0.f;
@@ -670,14 +750,15 @@ static void clear_margins(hsr_batch *b) {
     hipLaunchKernelGGL(k_clear_margins, grid1((size_t)b->ds.npair_sep * b->N), dim3(256), 0, b->stream, b->ds);
 }
 extern "C" int hsr_batch_set_persistent(hsr_batch *b, int on) {
+    NULLCHK(b);
     const bool want = on != 0 && b->persist_ok;
     if (want && !b->persist) { hipSetDevice(b->device); clear_margins(b); }      // the per-substep chain does not maintain the margins
     b->persist = want;
     return b->persist ? 1 : 0;
 }
-extern "C" int hsr_batch_is_persistent(const hsr_batch *b) { return b->persist ? 1 : 0; }
+extern "C" int hsr_batch_is_persistent(const hsr_batch *b) { NULLCHK(b); return b->persist ? 1 : 0; }
 extern "C" int hsr_batch_set_debug(hsr_batch *b, int on) { if (!b) return fail(HSR_EINVAL, "null batch"); b->debug_store = (on & 1) != 0; b->test_hooks = on & 6; return HSR_OK; }
-extern "C" int hsr_batch_set_schedule(hsr_batch *b, int on) { b->schedule = on != 0; return HSR_OK; }
+extern "C" int hsr_batch_set_schedule(hsr_batch *b, int on) { NULLCHK(b); b->schedule = on != 0; return HSR_OK; }
 extern "C" int hsr_batch_set_goals(hsr_batch *b, int n, const int *body_a, const int *body_b, const float *dist) {
     if (!b || n < 0 || n > 4 || (n > 0 && (!body_a || !body_b || !dist))) return fail(HSR_EINVAL, "hsr_batch_set_goals: 0..4 terms");
     for (int k = 0; k < n; k++)
@@ -726,6 +807,7 @@ static void launch_substep(hsr_batch *b, int mode, int goal_body, float geofence
 }
 
 extern "C" int hsr_batch_forward(hsr_batch *b) {
+    NULLCHK(b);
     HIPCHK(hipSetDevice(b->device));
     hipLaunchKernelGGL(k_clear_done, grid1(b->N), dim3(256), 0, b->stream, b->ds);
     launch_substep(b, 0, -1, 0.f, 1, b->stream, false);
@@ -735,6 +817,7 @@ extern "C" int hsr_batch_forward(hsr_batch *b) {
 }
 
 extern "C" int hsr_batch_reset(hsr_batch *b, const uint8_t *mask, const float *qpos0, const float *mocap) {
+    NULLCHK(b);
     HIPCHK(hipSetDevice(b->device));
     const size_t N = b->N;
     const int nq = b->dm.nq;
@@ -745,30 +828,26 @@ extern "C" int hsr_batch_reset(hsr_batch *b, const uint8_t *mask, const float *q
     if (off > b->stage_floats) return fail(HSR_EINVAL, "staging overflow in reset");
     if (mask) HIPCHK(hipMemcpyAsync(b->d_stage_u8, mask, N, hipMemcpyHostToDevice, b->stream));
     hipLaunchKernelGGL(k_reset, grid1(N), dim3(256), 0, b->stream, b->dm, b->ds, mask ? (const uint8_t *)b->d_stage_u8 : (const uint8_t *)nullptr,
-                       (const float *)d_q, (const float *)d_q0m, (const float *)d_m);
+                       (const float *)d_q, (const float *)d_q0m, (const float *)d_m, mask ? 1 : 0);
+    // the forward pass concerns the reset envs only (MujocoEnv.reset() touches one env, hsr/mujoco_env.py:83-85): with a mask the
+    // others stay parked as "done" for that pass, as in hsr_batch_reset_dev
+    launch_substep(b, 0, -1, 0.f, 1, b->stream, false);
+    hipLaunchKernelGGL(k_clear_done, grid1(N), dim3(256), 0, b->stream, b->ds);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(b->stream));
-    return hsr_batch_forward(b);
+    return HSR_OK;
 }
 
+// the forward pass after a masked reset concerns the reset envs only (the reference's reset() touches one env): the others are
+// parked as "done" for that pass by k_reset, so its kernels skip them (whole waves return when none of their envs was reset)
 // device-pointer reset: envs with d_mask[e] != 0 (or, when d_mask == NULL, the envs whose done flag was
 // latched by the last step) restart from d_qpos0[e] / d_mocap[e]; asynchronous; followed by forward.
-__global__ void k_mask_from_done(DevState s, uint8_t *mask) {
-    int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e < s.N) mask[e] = (uint8_t)(s.done[e] != 0);
-}
-// the forward pass after a masked reset concerns the reset envs only (the reference's reset() touches one env): the others are
-// parked as "done" for that pass, so its kernels skip them (whole waves return when none of their envs was reset)
-__global__ void k_park_unmasked(DevState s, const uint8_t *mask) {
-    int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e < s.N) s.done[e] = mask[e] ? 0 : 1;
-}
-extern "C" int hsr_batch_reset_dev(hsr_batch *b, const uint8_t *d_mask, const float *d_qpos0, const float *d_mocap) {
+extern "C" int hsr_batch_reset_dev(hsr_batch *b, const uint8_t *d_mask, const float *d_qpos0, const float *d_mocap) { NULLCHK(b);
     HIPCHK(hipSetDevice(b->device));
     const size_t N = b->N;
-    if (!d_mask) { hipLaunchKernelGGL(k_mask_from_done, grid1(N), dim3(256), 0, b->stream, b->ds, b->d_stage_u8); d_mask = b->d_stage_u8; }
-    hipLaunchKernelGGL(k_reset, grid1(N), dim3(256), 0, b->stream, b->dm, b->ds, d_mask, d_qpos0, (const float *)b->d_qpos0, d_mocap);
-    hipLaunchKernelGGL(k_park_unmasked, grid1(N), dim3(256), 0, b->stream, b->ds, d_mask);
+    // k_reset with park = 1 does all three jobs in one launch: mask = done flags (d_mask == NULL), reset of the masked envs, and the
+    // unmasked ones parked as "done" for the forward pass that follows
+    hipLaunchKernelGGL(k_reset, grid1(N), dim3(256), 0, b->stream, b->dm, b->ds, d_mask, d_qpos0, (const float *)b->d_qpos0, d_mocap, 1);
     launch_substep(b, 0, -1, 0.f, 0, b->stream, false);
     hipLaunchKernelGGL(k_clear_done, grid1(N), dim3(256), 0, b->stream, b->ds);
     HIPCHK(hipGetLastError());
@@ -792,7 +871,7 @@ static int to_host_aos(hsr_batch *b, float *host, const float *src, int rows) {
     return HSR_OK;
 }
 
-extern "C" int hsr_batch_get_state(hsr_batch *b, float *time, float *qpos, float *qvel) {
+extern "C" int hsr_batch_get_state(hsr_batch *b, float *time, float *qpos, float *qvel) { NULLCHK(b);
     HIPCHK(hipSetDevice(b->device));
     int rc;
     if (time && (rc = to_host_aos(b, time, b->ds.time, 1))) return rc;
@@ -800,7 +879,7 @@ extern "C" int hsr_batch_get_state(hsr_batch *b, float *time, float *qpos, float
     if (qvel && (rc = to_host_aos(b, qvel, b->ds.qvel, b->dm.nv))) return rc;
     return HSR_OK;
 }
-extern "C" int hsr_batch_set_state(hsr_batch *b, const float *time, const float *qpos, const float *qvel) {
+extern "C" int hsr_batch_set_state(hsr_batch *b, const float *time, const float *qpos, const float *qvel) { NULLCHK(b);
     HIPCHK(hipSetDevice(b->device));
     clear_margins(b);                     // positions jump: the separation margins of the convex pairs are void
     int rc;
@@ -809,9 +888,9 @@ extern "C" int hsr_batch_set_state(hsr_batch *b, const float *time, const float 
     if (qvel && (rc = to_device_soa(b, b->ds.qvel, qvel, b->dm.nv))) return rc;
     return hsr_batch_forward(b);
 }
-extern "C" int hsr_batch_set_mocap(hsr_batch *b, const float *mocap) { HIPCHK(hipSetDevice(b->device)); return to_device_soa(b, b->ds.mocap, mocap, 3); }
-extern "C" int hsr_batch_set_warmstart(hsr_batch *b, const float *w) { HIPCHK(hipSetDevice(b->device)); return to_device_soa(b, b->ds.warm, w, b->dm.nv); }
-extern "C" int hsr_batch_get_warmstart(hsr_batch *b, float *w) { HIPCHK(hipSetDevice(b->device)); return to_host_aos(b, w, b->ds.warm, b->dm.nv); }
+extern "C" int hsr_batch_set_mocap(hsr_batch *b, const float *mocap) { NULLCHK(b); HIPCHK(hipSetDevice(b->device)); return to_device_soa(b, b->ds.mocap, mocap, 3); }
+extern "C" int hsr_batch_set_warmstart(hsr_batch *b, const float *w) { NULLCHK(b); HIPCHK(hipSetDevice(b->device)); return to_device_soa(b, b->ds.warm, w, b->dm.nv); }
+extern "C" int hsr_batch_get_warmstart(hsr_batch *b, float *w) { NULLCHK(b); HIPCHK(hipSetDevice(b->device)); return to_host_aos(b, w, b->ds.warm, b->dm.nv); }
 
 // Wave packing of the persistent kernel (on by default; HSR_SCHEDULE=0 or hsr_batch_set_schedule(b, 0) keeps the identity packing).
 // A launch ends with the wave that holds the hardest env (the one that needs the most Newton iterations per substep), and a wave
@@ -868,8 +947,9 @@ extern "C" int hsr_batch_step_dev(hsr_batch *b, const float *d_ctrl, int n_subst
         b->kev.clear();
         HIPCHK(hipEventRecord(b->ev0, st));
     }
-    hipLaunchKernelGGL(k_begin_step, grid1(N), dim3(256), 0, st, b->ds, d_ctrl, b->dm.nu);
-    if (b->persist && n_substeps > 0) {
+    const bool fused = b->persist && n_substeps > 0;      // the persistent kernel reads ctrl and writes obs / reward / done / nsteps itself
+    if (!fused) hipLaunchKernelGGL(k_begin_step, grid1(N), dim3(256), 0, st, b->ds, d_ctrl, b->dm.nu);
+    if (fused) {
         const int epb = 64 / b->group;
         if (b->profiling) { hipEvent_t ev; for (int k = 0; k < 3; k++) { hipEventCreate(&ev); hipEventRecord(ev, st); b->kev.push_back(ev); } }
         if (!b->d_dm) {
@@ -881,7 +961,11 @@ extern "C" int hsr_batch_step_dev(hsr_batch *b, const float *d_ctrl, int n_subst
         if (sched) hipLaunchKernelGGL(k_schedule, dim3((N + SCHED_CHUNK - 1) / SCHED_CHUNK), dim3(1024), 0, st, b->ds, epb, b->d_slot_env);
         DevState dsl = b->ds;
         dsl.slot_env = sched ? b->d_slot_env : nullptr;
-        hipLaunchKernelGGL(persist_kernel(b->group, b->dm.nv, b->dm.ndense, b->persist_tg), dim3((N + epb - 1) / epb), dim3(64), b->persist_lds_bytes, st, (const DevModel *)b->d_dm, dsl, n_substeps, goal_body, geofence, (b->debug_store ? 1 : 0) | b->test_hooks);
+        const StepIO io{d_ctrl, d_obs, d_reward, d_done, d_nsteps};
+        hipEvent_t k0 = nullptr, k1 = nullptr;
+        if (b->kernel_log) { hipEventCreate(&k0); hipEventCreate(&k1); hipEventRecord(k0, st); }
+        hipLaunchKernelGGL(persist_kernel(b->group, b->dm.nv, b->dm.ndense, b->persist_tg), dim3((N + epb - 1) / epb), dim3(64), b->persist_lds_bytes, st, (const DevModel *)b->d_dm, dsl, n_substeps, goal_body, geofence, (b->debug_store ? 1 : 0) | b->test_hooks, io);
+        if (b->kernel_log) { hipEventRecord(k1, st); b->klog.push_back({k0, k1}); }
         if (b->profiling) { hipEvent_t ev; hipEventCreate(&ev); hipEventRecord(ev, st); b->kev.push_back(ev); }   // slots 0,1 empty; slot 2 = the persistent kernel
     } else if (b->use_graph && !b->profiling && n_substeps > 0) {
         GraphKey key{n_substeps, goal_body, geofence};
@@ -901,12 +985,14 @@ extern "C" int hsr_batch_step_dev(hsr_batch *b, const float *d_ctrl, int n_subst
     } else {
         for (int i = 0; i < n_substeps; i++) launch_substep(b, 1, goal_body, geofence, 0, st, b->profiling);
     }
-    if (d_obs) {
-        const int nq = b->dm.nq, nv = b->dm.nv;
-        hipLaunchKernelGGL(k_soa_to_aos, grid1((size_t)nq * N), dim3(256), 0, st, d_obs, (const float *)b->ds.qpos, nq, N, nq + nv, 0);
-        hipLaunchKernelGGL(k_soa_to_aos, grid1((size_t)nv * N), dim3(256), 0, st, d_obs, (const float *)b->ds.qvel, nv, N, nq + nv, nq);
+    if (!fused) {
+        if (d_obs) {
+            const int nq = b->dm.nq, nv = b->dm.nv;
+            hipLaunchKernelGGL(k_soa_to_aos, grid1((size_t)nq * N), dim3(256), 0, st, d_obs, (const float *)b->ds.qpos, nq, N, nq + nv, 0);
+            hipLaunchKernelGGL(k_soa_to_aos, grid1((size_t)nv * N), dim3(256), 0, st, d_obs, (const float *)b->ds.qvel, nv, N, nq + nv, nq);
+        }
+        hipLaunchKernelGGL(k_end_step, grid1(N), dim3(256), 0, st, b->ds, d_reward, d_done, d_nsteps);
     }
-    hipLaunchKernelGGL(k_end_step, grid1(N), dim3(256), 0, st, b->ds, d_reward, d_done, d_nsteps);
     HIPCHK(hipGetLastError());
     if (b->profiling) {
         HIPCHK(hipEventRecord(b->ev1, st));
@@ -940,7 +1026,7 @@ extern "C" int hsr_batch_step(hsr_batch *b, const float *ctrl, int n_substeps, i
     return HSR_OK;
 }
 
-extern "C" int hsr_batch_body_xpos(hsr_batch *b, int body_id, float *out) {
+extern "C" int hsr_batch_body_xpos(hsr_batch *b, int body_id, float *out) { NULLCHK(b);
     if (body_id < 0 || body_id >= b->dm.nbody) return fail(HSR_EINVAL, "body id out of range");
     HIPCHK(hipSetDevice(b->device));
     hipLaunchKernelGGL(k_body_xpos, grid1(b->N), dim3(256), 0, b->stream, b->dm, b->ds, body_id, b->d_stage);
@@ -968,7 +1054,7 @@ extern "C" int hsr_batch_obs_openai(hsr_batch *b, const int *ids, float *out) {
     return HSR_OK;
 }
 
-extern "C" int hsr_batch_bad_state(hsr_batch *b, uint8_t *out) {
+extern "C" int hsr_batch_bad_state(hsr_batch *b, uint8_t *out) { NULLCHK(b);
     HIPCHK(hipSetDevice(b->device));
     std::vector<int> tmp(b->N);
     HIPCHK(hipMemcpyAsync(tmp.data(), b->ds.bad, (size_t)b->N * sizeof(int), hipMemcpyDeviceToHost, b->stream));
@@ -978,7 +1064,7 @@ extern "C" int hsr_batch_bad_state(hsr_batch *b, uint8_t *out) {
     return any ? HSR_EBADSTATE : HSR_OK;
 }
 
-extern "C" int hsr_batch_get_field(hsr_batch *b, int field, float *out) {
+extern "C" int hsr_batch_get_field(hsr_batch *b, int field, float *out) { NULLCHK(b);
     HIPCHK(hipSetDevice(b->device));
     const DevModel &d = b->dm;
     const size_t N = b->N;
@@ -1010,7 +1096,7 @@ extern "C" int hsr_batch_get_field(hsr_batch *b, int field, float *out) {
 }
 
 // diagnostic builds (-DHSR_PHASE_TIMING): read and clear the per-phase cycle sums of k_solve_g
-extern "C" int hsr_batch_phase_cycles(hsr_batch *b, unsigned long long *out /*[32]*/) {
+extern "C" int hsr_batch_phase_cycles(hsr_batch *b, unsigned long long *out /*[32]*/) { NULLCHK(b);
     HIPCHK(hipSetDevice(b->device));
     HIPCHK(hipStreamSynchronize(b->stream));
     HIPCHK(hipMemcpy(out, b->ds.phase_cyc, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
@@ -1019,7 +1105,7 @@ extern "C" int hsr_batch_phase_cycles(hsr_batch *b, unsigned long long *out /*[3
 }
 
 // diagnostic builds: per-workgroup (start, end) s_memrealtime stamps and HW_ID / XCC_ID of the last persistent launch
-extern "C" int hsr_batch_block_times(hsr_batch *b, unsigned long long *out, int nblocks) {
+extern "C" int hsr_batch_block_times(hsr_batch *b, unsigned long long *out, int nblocks) { NULLCHK(b);
     HIPCHK(hipSetDevice(b->device));
     HIPCHK(hipStreamSynchronize(b->stream));
     if (nblocks > 8192) nblocks = 8192;
@@ -1027,7 +1113,7 @@ extern "C" int hsr_batch_block_times(hsr_batch *b, unsigned long long *out, int 
     return HSR_OK;
 }
 
-extern "C" int hsr_batch_last_timing(hsr_batch *b, float *total_ms, float *kernel_ms, int *launches) {
+extern "C" int hsr_batch_last_timing(hsr_batch *b, float *total_ms, float *kernel_ms, int *launches) { NULLCHK(b);
     if (total_ms) *total_ms = b->last_total_ms;
     for (int k = 0; k < 3; k++) { if (kernel_ms) kernel_ms[k] = b->last_kernel_ms[k]; if (launches) launches[k] = b->last_launches[k]; }
     return HSR_OK;

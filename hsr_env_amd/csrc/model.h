@@ -37,6 +37,10 @@ struct DevModel {
     const float *act_gear, *act_kp, *act_ctrlrange, *act_forcerange;
 };
 
+// env-step inputs / outputs of the caller (hsr_batch_step_dev), env-major as the C-ABI hands them over: the persistent kernel reads ctrl
+// and writes obs / reward / done / nsteps itself (ctrl == NULL: the state arrays s.ctrl / s.done are used as they are)
+struct StepIO { const float *ctrl; float *obs, *reward; uint8_t *done; int32_t *nsteps; };
+
 // per-batch buffers; every array is [rows][N] with the env index fastest (coalesced across lanes)
 struct DevState {
     int N;
@@ -56,6 +60,8 @@ struct DevState {
     int *pair_count, *pair_list;   // per-pair work lists of the narrowphase: count[npair_pad], list[npair][N] env ids
     float *sepax;             // [4 npair][N] per (pair, env) of the MPR pairs: cached separating direction (0 = none), then the separation left along it
     int npair_sep;            // rows of sepax / 4
+    int *septick, *tick;      // septick[npair][N]: the env's substep count (tick[N]) when the margin of (pair, env) was last brought up to date;
+                              // a margin is valid on the very next substep of its env only (a pair culled in between moves unaccounted)
     unsigned *pair_pack;      // [npair padded to 8] packed sphere-cull records and [ngeom][8] narrowphase constants: global copies of the two
     float *geom_c;            // LDS tables of the persistent kernel, read instead of them by its TG instances (models whose LDS would not fit 8 workgroups per CU)
     // dynamics / solver outputs kept for introspection

@@ -47,7 +47,7 @@ template <int G> struct PersistLayout {
 // NDT (EXACT only, else -1): ndense at compile time - the dofs from NDT on never couple to another dof in M (free bodies)
 // TG: pair records / geom constants read from global memory instead of LDS (for models with many pairs: 8 workgroups per CU)
 template <int G, int NVT, bool EXACT, int NDT = -1, bool TG = false>
-__global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restrict__ mp, DevState s, int n_substeps, int goal_body, float geofence, int flags) {
+__global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restrict__ mp, DevState s, int n_substeps, int goal_body, float geofence, int flags, StepIO io) {
     // the ~90 model fields stay in (constant-cached) memory and are read where they are used, instead of sitting in - and
     // spilling from - SGPRs for the whole launch
     const DevModel &m = *mp;
@@ -95,7 +95,8 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
     if (tid0 < m.nlink && tid0 < NLMAX) { sMask[tid0] = m.link_dofmask[tid0]; sMass[tid0] = m.link_mass[tid0]; }
     __shared__ unsigned char sDofLink[32];
     __shared__ int sEnv[64 / G];                       // env index of every lane group of this workgroup (wave packing: DevState::slot_env)
-    if (tid0 % G == 0) { const int er = s.slot_env ? s.slot_env[blockIdx.x * EPB + tid0 / G] : blockIdx.x * EPB + tid0 / G; sEnv[tid0 / G] = (er >= 0 && er < N) ? er : 0; }
+    __shared__ int sTick[64 / G];                      // substeps every env of this workgroup has run since its batch was created (DevState::tick): stamps of the separation margins
+    if (tid0 % G == 0) { const int er = s.slot_env ? s.slot_env[blockIdx.x * EPB + tid0 / G] : blockIdx.x * EPB + tid0 / G; sEnv[tid0 / G] = (er >= 0 && er < N) ? er : 0; sTick[tid0 / G] = s.tick[(er >= 0 && er < N) ? er : 0]; }
     if (tid0 < nv) sDofLink[tid0] = (unsigned char)m.dof_link[tid0];
     if (tid0 < m.nlink) kin2_store(m, tid0, lds + L.oKin + KIN2_FLOATS * tid0);
     // geom cache: constants of every geom, placements of the static ones (world link: identity pose)
@@ -127,7 +128,9 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
     int nsteps_e = 0;
     {
         PERSIST_LANE_VIEW(tid0)
-        done = !in_range || s.done[e] != 0;
+        // HSREnv.step begins with `ctrl[:] = action` and a fresh done flag (hsr/env.py:116,124): with the caller's arrays at hand
+        // (io.ctrl) the kernel does both itself instead of a k_begin_step launch in front of it
+        done = !in_range || (io.ctrl ? false : s.done[e] != 0);
         if (c < nq) qpos_c = s.qpos[(size_t)c * N + e];
         if (isdof) { qvel_c = s.qvel[(size_t)c * N + e]; warm_c = s.warm[(size_t)c * N + e]; }
         goal = mk3(s.mocap[e], s.mocap[N + e], s.mocap[2 * N + e]);
@@ -149,7 +152,8 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
 #pragma unroll
             for (int j = 0; j < 5; j++) lim_si[j] = m.dof_solimp[5 * c + j];
             if (my_act >= 0) {
-                my_ctrl = s.ctrl[(size_t)my_act * N + e];
+                if (io.ctrl) { my_ctrl = in_range ? io.ctrl[(size_t)e * m.nu + my_act] : 0.f; if (in_range) s.ctrl[(size_t)my_act * N + e] = my_ctrl; }
+                else my_ctrl = s.ctrl[(size_t)my_act * N + e];
                 act_p[0] = m.act_kp[my_act]; act_p[1] = m.act_gear[my_act];
                 act_p[2] = m.act_ctrlrange[2 * my_act]; act_p[3] = m.act_ctrlrange[2 * my_act + 1];
                 act_p[4] = m.act_forcerange[2 * my_act]; act_p[5] = m.act_forcerange[2 * my_act + 1];
@@ -169,6 +173,7 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
         PERSIST_LANE_VIEW(tid_l)
         const bool valid = !done;
         if (!wave_any(valid)) break;
+        if (valid && c == 0) sTick[g] += 1;      // read by the convex-pair section of ANY lane group, several wave_syncs further down
         int bad = 0;                 // per substep; only a live env's flag is kept
         asm volatile("" ::: "memory");   // model constants are re-read (L2 hits) every substep instead of living in - and spilling from - registers
         // placement constants of this lane's moving geom: fetched now, consumed after the kinematics (the L2 latency hides behind it)
@@ -338,7 +343,7 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
             wave_sync();
             PHASE(19);
 #pragma unroll
-            for (int j = 0; j < EPB; j++) if (g == j && nit_env[j] > 64) { bad = 1; cap_item += valid ? 1 : 0; }      // more than 64 surviving pairs in ONE env: its contacts beyond them are dropped
+            for (int j = 0; j < EPB; j++) if (g == j && nit_env[j] > 64) cap_item += valid ? 1 : 0;      // more than 64 surviving pairs in ONE env: its contacts beyond them are dropped (a capacity event, counted in capstat[2]; NOT a diverged state)
             DBGCNT(2, nitems);
             wave_sync();
             for (int ib = 0; ib < nitems; ib += 64) {
@@ -383,11 +388,17 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
                             // temporal coherence: the direction d that separated the pair last time, and how much of that
                             // separation is left after the geoms' moves since (upper bounds, geom cache slot 15): while it is
                             // positive the pair is still separated along d and nothing is scanned; otherwise both hulls are scanned
-                            // along d and the margin is refreshed; MPR runs only when d no longer separates
+                            // along d and the margin is refreshed; MPR runs only when d no longer separates.
+                            // The margin is only worth anything if it was brought up to date on the env's PREVIOUS substep: a pair that
+                            // was culled (spheres, boxes, item cap) in between has moved by amounts nobody subtracted - its stamp
+                            // (the env's substep count at the last visit) then differs from tick - 1 and the margin counts as 0.
                             PHASE_M(26);
                             float *sx = s.sepax + (size_t)(4 * (it2 & 0x3fff)) * N + sEnv[it2 >> 14];
                             const v3 d = mk3(sx[0], sx[N], sx[2 * (size_t)N]);
                             float mg = sx[3 * (size_t)N];
+                            int *stampp = s.septick + (size_t)(it2 & 0x3fff) * N + sEnv[it2 >> 14];
+                            const int tick_now = sTick[it2 >> 14];
+                            if (*stampp != tick_now - 1) mg = 0.f;
                             {
                                 const unsigned pk2 = sPair[it2 & 0x3fff];
                                 const float *Ei2 = lds + (size_t)(it2 >> 14) * L.envf;
@@ -422,7 +433,7 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
                                     sx[0] = sep.x; sx[N] = sep.y; sx[2 * (size_t)N] = sep.z;
                                 }
                             }
-                            if ((tid & (MW - 1)) == 0) sx[3 * (size_t)N] = mg;
+                            if ((tid & (MW - 1)) == 0) { sx[3 * (size_t)N] = mg; *stampp = tick_now; }
                             if ((tid & (MW - 1)) == 0) *cntp = (unsigned char)o2.cnt;
                             PHASE_M(30);
                         }
@@ -519,9 +530,15 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
     }
     // ---------------- write the state back (struct-of-arrays)
     PERSIST_LANE_VIEW(tid0)
-    if (in_range && !(s.done[e] != 0 && nsteps_e == 0)) {
+    if (in_range && (io.ctrl || !(s.done[e] != 0 && nsteps_e == 0))) {
         if (c < nq) s.qpos[(size_t)c * N + e] = qpos_c;
         if (isdof) { s.qvel[(size_t)c * N + e] = qvel_c; s.warm[(size_t)c * N + e] = warm_c; }
+        // a-5 observation = concat(qpos, qvel) (hsr/env.py:111-113), env-major, straight from the registers
+        if (io.obs) {
+            float *o = io.obs + (size_t)e * (nq + nv);
+            if (c < nq) o[c] = qpos_c;
+            if (isdof) o[nq + c] = qvel_c;
+        }
         const float bsum = gsum<G>((float)bad_acc);
         if (c == 0) {
             if (cap_con) atomicAdd(&s.capstat[0], (unsigned long long)cap_con);
@@ -529,9 +546,18 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
             if (cap_item) atomicAdd(&s.capstat[2], (unsigned long long)cap_item);
             atomicAdd(&s.capstat[3], (unsigned long long)nsub_run);
             s.trips[e] = own_trips;
-            s.time[e] = time_e; s.nsteps[e] = s.nsteps[e] + nsteps_e;
+            s.tick[e] = sTick[g];
+            s.time[e] = time_e;
             if (bsum > 0) s.bad[e] = 1;
-            if (done) s.done[e] = 1;
+            if (io.ctrl) {
+                s.nsteps[e] = nsteps_e; s.done[e] = done ? 1 : 0;
+                if (io.reward) io.reward[e] = done ? 1.f : 0.f;          // reward = float(success) (hsr/env.py:133)
+                if (io.done) io.done[e] = done ? 1 : 0;
+                if (io.nsteps) io.nsteps[e] = nsteps_e;
+            } else {
+                s.nsteps[e] = s.nsteps[e] + nsteps_e;
+                if (done) s.done[e] = 1;
+            }
         }
     }
 #ifdef HSR_PHASE_TIMING

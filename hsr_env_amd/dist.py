@@ -63,3 +63,43 @@ def all_gather_step(packed_local, world: int, out=None, equal_shards=None):
     bufs = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(bufs, pad)
     return torch.cat([b[:n] for b, n in zip(bufs, sizes)], dim=0)
+
+
+class StepGather:
+    """The per-env-step exchange of the sharded run: pack obs / reward / done of the local shard into one fp32
+    buffer [N_local, nq+nv+2] and all-gather it into [world * N_local, nq+nv+2], on torch's CURRENT stream - bench.py makes that the
+    batch's own HIP stream (torch.cuda.ExternalStream), so the collective is ordered after the env-step kernel without a host sync.
+    Equal shards only (the weak-scaling layout); the buffers are allocated once.  With `always=True` the collective is issued even
+    for a single rank (RCCL accepts a one-rank communicator): the GPU test uses that to execute this exact code path on one GPU."""
+
+    def __init__(self, n_local: int, nobs: int, world: int, device, always: bool = False):
+        import torch
+        self.world, self.nobs, self.always = world, nobs, always
+        self.pack = torch.empty((n_local, nobs + 2), dtype=torch.float32, device=device)
+        self.all = torch.empty((world * n_local, nobs + 2), dtype=torch.float32, device=device) if (world > 1 or always) else self.pack
+
+    def __call__(self, obs, reward, done):
+        import torch.distributed as dist
+        nobs = self.nobs
+        self.pack[:, :nobs] = obs
+        self.pack[:, nobs] = reward
+        self.pack[:, nobs + 1] = done
+        if (self.world > 1 or self.always) and dist.is_initialized():
+            if dist.get_backend() == "gloo":
+                host = self.pack.cpu()
+                bufs = [host.new_empty(host.shape) for _ in range(self.world)]
+                dist.all_gather(bufs, host)
+                self.all.copy_(__import__("torch").cat(bufs, dim=0))
+            else:
+                dist.all_gather_into_tensor(self.all, self.pack)
+        return self.all
+
+
+def init_process_group(backend: str, device=None):
+    """env:// rendezvous (RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT from the launcher); "nccl" is RCCL on ROCm and is bound to
+    `device` at creation (device_id), as the eager-init path of torch requires for collectives on a non-default stream."""
+    import torch.distributed as dist
+    if backend == "nccl":
+        dist.init_process_group("nccl", device_id=device)
+    else:
+        dist.init_process_group(backend)

@@ -112,6 +112,10 @@ int hsr_batch_get_field(hsr_batch *b, int field, float *out);
  * enable with hsr_batch_set_profiling(b, 1).  kernel order: kinematics, collide, solve */
 int hsr_batch_set_profiling(hsr_batch *b, int on);
 int hsr_batch_last_timing(hsr_batch *b, float *total_ms, float *kernel_ms /*[3]*/, int *launches /*[3]*/);
+/* hsr_batch_set_profiling(b, 2): log an event pair around EVERY launch of the persistent kernel without synchronising (what bench.py
+ * times its roofline with).  hsr_batch_kernel_times synchronises, writes the durations (ms) of the launches logged since the last
+ * call into out_ms[0..cap) and returns how many there were. */
+int hsr_batch_kernel_times(hsr_batch *b, float *out_ms, int cap);
 /* use a captured hipGraph for the substep loop of the per-substep-kernel path (default on) */
 int hsr_batch_set_graph(hsr_batch *b, int on);
 /* whole env-step in ONE persistent kernel (default on when the model fits: nv <= 32, LDS budget); returns the

@@ -74,3 +74,73 @@ def test_product_package_never_imports_oracle():
     for f in (ROOT / "hsr_env_amd").rglob("*"):
         if f.suffix in (".py", ".h", ".hip", ".cpp"):
             assert not pat.search(f.read_text()), f
+
+
+def test_model_load_refuses_truncated_and_corrupted_blobs(lib, models):
+    """hsr_model_load treats the blob as untrusted input (reference convention: a bad model file is an IOError,
+    hsr/mujoco_env.py:30-31 - never a crash): every truncation point and a set of corrupted headers return HSR_EBLOB."""
+    import struct
+    raw = models["cfg3"].to_bytes()
+    lib.hsr_model_load.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_void_p)]
+    lib.hsr_model_destroy.argtypes = [C.c_void_p]
+    n = struct.unpack("<I", raw[8:12])[0]
+    esz = 72
+    jl = struct.unpack("<Q", raw[16 + n * esz:16 + n * esz + 8])[0]
+    data_off = 16 + n * esz + 8 + jl
+
+    def load(buf):
+        h = C.c_void_p()
+        rc = lib.hsr_model_load(bytes(buf), len(buf), C.byref(h))
+        if rc == 0:
+            lib.hsr_model_destroy(h)
+        return rc
+
+    assert load(raw) == 0
+    # truncations: inside the header, the entry table, the json, the data, and one byte short
+    for cut in (8, 12, 15, 16, 16 + esz, 16 + n * esz, 16 + n * esz + 4, data_off - 8, data_off, data_off + 64, len(raw) // 2, len(raw) - 8, len(raw) - 1):
+        assert load(raw[:cut]) == -2, cut
+    # entry count / json length / entry offsets and sizes that point outside the file
+    bad = bytearray(raw); bad[8:12] = struct.pack("<I", 0x7fffffff); assert load(bad) == -2
+    bad = bytearray(raw); bad[8:12] = struct.pack("<I", n + 1); assert load(bad) == -2
+    bad = bytearray(raw); bad[16 + n * esz:16 + n * esz + 8] = struct.pack("<Q", 1 << 60); assert load(bad) == -2
+    for i in range(n):
+        e = 16 + i * esz
+        bad = bytearray(raw); bad[e + 56:e + 64] = struct.pack("<Q", len(raw)); assert load(bad) == -2, i          # off beyond the data
+        bad = bytearray(raw); bad[e + 64:e + 72] = struct.pack("<Q", (1 << 63) + 8); assert load(bad) == -2, i     # nbytes wraps around
+    # an entry that is shorter than the model sizes say (dof_axis cut to one row)
+    names = [raw[16 + i * esz:16 + i * esz + 32].rstrip(b"\0").decode() for i in range(n)]
+    e = 16 + names.index("dof_axis") * esz
+    bad = bytearray(raw); bad[e + 64:e + 72] = struct.pack("<Q", 24); assert load(bad) == -2
+    # sizes that disagree with the tables (nv claims 64 dofs), and an index table pointing outside its target
+    e = 16 + names.index("sizes") * esz
+    off = struct.unpack("<Q", raw[e + 56:e + 64])[0]
+    bad = bytearray(raw); bad[data_off + off + 4:data_off + off + 8] = struct.pack("<i", 64); assert load(bad) == -2
+    bad = bytearray(raw); bad[data_off + off + 4:data_off + off + 8] = struct.pack("<i", -3); assert load(bad) == -2
+    e = 16 + names.index("pair_geom1") * esz
+    off = struct.unpack("<Q", raw[e + 56:e + 64])[0]
+    bad = bytearray(raw); bad[data_off + off:data_off + off + 4] = struct.pack("<i", 9999); assert load(bad) == -2
+    # a name field without a terminating NUL is read as 32 bytes, not beyond
+    bad = bytearray(raw); bad[16:48] = b"x" * 32; assert load(bad) == -2
+
+
+def test_null_handles_are_refused(lib):
+    """Every hsr_batch_* entry point checks its handle (round-2 finding: four getters dereferenced NULL)."""
+    vp = C.c_void_p
+    for name in ("hsr_batch_size", "hsr_batch_sync", "hsr_batch_forward", "hsr_batch_is_persistent"):
+        f = getattr(lib, name); f.argtypes = [vp]
+        assert f(None) == -1, name
+    for name in ("hsr_batch_set_profiling", "hsr_batch_set_graph", "hsr_batch_set_persistent", "hsr_batch_set_schedule", "hsr_batch_set_debug"):
+        f = getattr(lib, name); f.argtypes = [vp, C.c_int]
+        assert f(None, 1) == -1, name
+    lib.hsr_batch_stream.argtypes = [vp]; lib.hsr_batch_stream.restype = vp
+    assert lib.hsr_batch_stream(None) is None
+    lib.hsr_batch_last_timing.argtypes = [vp, vp, vp, vp]
+    assert lib.hsr_batch_last_timing(None, None, None, None) == -1
+    lib.hsr_batch_reset.argtypes = [vp, vp, vp, vp]
+    assert lib.hsr_batch_reset(None, None, None, None) == -1
+    lib.hsr_batch_get_state.argtypes = [vp, vp, vp, vp]
+    assert lib.hsr_batch_get_state(None, None, None, None) == -1
+    lib.hsr_batch_body_xpos.argtypes = [vp, C.c_int, vp]
+    assert lib.hsr_batch_body_xpos(None, 0, None) == -1
+    lib.hsr_batch_destroy.argtypes = [vp]; lib.hsr_batch_destroy.restype = None
+    lib.hsr_batch_destroy(None)

@@ -80,6 +80,10 @@ def test_bench_starts_its_own_ranks():
     assert r.returncode == 0, r.stderr
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["RANK"] == "0" and line["WORLD_SIZE"] == "3" and line["MASTER_ADDR"] == "127.0.0.1" and int(line["MASTER_PORT"]) > 0
-    # a failing rank fails the launch: without a GPU every rank exits non-zero
-    r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env, capture_output=True, text=True, timeout=300)
-    assert r.returncode != 0
+    # a failing rank fails the launch AND takes the others down: rank 1 exits at once, rank 0 and 2 would wait two minutes (like a
+    # rank stuck in the rendezvous of a peer that died) - the launcher returns the failure within seconds and leaves no child behind
+    import time
+    t0 = time.time()
+    r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "3", "--launch-check", "--fail-rank", "1"], env=env, capture_output=True, text=True, timeout=100)
+    assert r.returncode == 3, (r.returncode, r.stderr)
+    assert time.time() - t0 < 30

@@ -547,3 +547,90 @@ def test_several_goals_all_in_range(models):
             assert dn == bool(done[e]) and abs(k - int(ns[e])) <= (1 if dn else 0), (persistent, e, k, int(ns[e]), dn, bool(done[e]))
         assert done.any() and not done.all()
         env.close()
+
+
+def test_rccl_all_gather_on_the_batch_stream_one_rank(models):
+    """The exchange step of the sharded run (hsr_env_amd.dist.StepGather: pack + all_gather_into_tensor, backend "nccl" = RCCL, the
+    process group bound to the device, issued on the batch's own HIP stream through torch.cuda.ExternalStream) executed on the one
+    GPU there is: a one-rank communicator, so that the first multi-GPU run is not the first execution of this code.  The gathered
+    buffer must equal obs | reward | done of the step, with no host synchronisation between the env-step and the collective."""
+    import os
+    import socket
+    import torch
+    import torch.distributed as dist
+    from hsr_env_amd import dist as hd
+    m = models["cfg2"]
+    n = 256
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    hd.init_process_group("nccl", dev)
+    try:
+        assert dist.get_backend() == "nccl" and dist.get_world_size() == 1
+        rng = np.random.default_rng(5)
+        q, v, ctrl = random_states(m, n, rng)
+        sim = hs.BatchSim(m, n)
+        sim.set_state(np.zeros(n), q, v)
+        nobs = m.nq + m.nv
+        d_ctrl = torch.from_numpy(ctrl.astype(np.float32)).to(dev)
+        d_obs = torch.empty((n, nobs), dtype=torch.float32, device=dev)
+        d_rew = torch.empty(n, dtype=torch.float32, device=dev)
+        d_done = torch.empty(n, dtype=torch.uint8, device=dev)
+        d_ns = torch.empty(n, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        ext = torch.cuda.ExternalStream(sim.stream_ptr(), device=dev)
+        with torch.cuda.stream(ext):
+            gather = hd.StepGather(n, nobs, 1, dev, always=True)
+            for _ in range(3):
+                sim.step_dev(d_ctrl.data_ptr(), 25, m.body_id("block0"), 0.5, d_obs.data_ptr(), d_rew.data_ptr(), d_done.data_ptr(), d_ns.data_ptr())
+                out = gather(d_obs, d_rew, d_done)
+        sim.sync()
+        torch.cuda.synchronize()
+        assert out.data_ptr() != gather.pack.data_ptr() and out.shape == (n, nobs + 2)
+        o, r, d = hd.unpack_step(out)
+        assert torch.equal(o, d_obs) and torch.equal(r, d_rew) and torch.equal(d, d_done > 0)
+        t, qq, vv = sim.get_state()
+        assert np.array_equal(o.cpu().numpy(), np.concatenate([qq, vv], axis=1))
+        assert int(d_ns.min()) >= 1
+        sim.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_step_outputs_written_by_the_persistent_kernel(models):
+    """hsr_batch_step_dev with the persistent kernel: ctrl is read and obs / reward / done / nsteps are written by that kernel itself
+    (no k_begin_step / k_soa_to_aos / k_end_step launches).  Checked against the state arrays and against the per-substep chain,
+    which still goes through those kernels: identical outputs for the same inputs, also for envs that finish early and with
+    output pointers left NULL."""
+    import torch
+    m = models["cfg3"]
+    n = 200
+    rng = np.random.default_rng(77)
+    q, v, ctrl = random_states(m, n, rng)
+    goal = np.tile([0.0, 0.0, 0.422], (n, 1)).astype(np.float32)
+    outs = []
+    for persistent in (True, False):
+        sim = hs.BatchSim(m, n)
+        sim.set_persistent(persistent)
+        assert sim.is_persistent() == persistent
+        sim.set_mocap(goal)
+        sim.set_state(np.zeros(n), q, v)
+        obs, rew, done, ns = sim.step(ctrl, 30, m.body_id("block0"), 0.08)
+        t, qq, vv = sim.get_state()
+        assert np.array_equal(obs, np.concatenate([qq, vv], axis=1))
+        assert np.array_equal(rew, done.astype(np.float32))
+        assert ((ns == 30) | (done > 0)).all() and (ns >= 1).all()
+        # a second step with every output pointer NULL runs and leaves a consistent state
+        d_ctrl = torch.from_numpy(ctrl.astype(np.float32)).cuda()
+        sim.step_dev(d_ctrl.data_ptr(), 5, m.body_id("block0"), 0.08, None, None, None, None)
+        sim.sync()
+        t2, q2, v2 = sim.get_state()
+        assert np.isfinite(q2).all() and (t2 >= t).all() and (t2 <= t + 5 * 0.002 + 1e-6).all()
+        outs.append((obs, rew, done, ns))
+        sim.close()
+    assert 0 < outs[0][2].sum() < n, "the case needs both early exits and full env-steps"
+    assert np.array_equal(outs[0][2], outs[1][2]) and np.array_equal(outs[0][3], outs[1][3])
+    assert np.abs(outs[0][0] - outs[1][0]).max() < 1e-5
