@@ -265,6 +265,10 @@ __global__ void k_build_tables(DevModel m, DevState s) {
 // the persistent kernel instantiations: (lanes per env, compile-time bound on nv)
 typedef void (*persist_fn)(const DevModel *, DevState, int, int, float, int, StepIO);
 static persist_fn persist_kernel(int group, int nv, int ndense, bool tg = false) {
+#ifdef HSR_DEV_CFG3
+    // development builds (tools/build_variants.py): only the cfg3 instance is compiled - a sixth of the build time
+    return (!tg && group == 16 && nv == 13 && ndense == 7) ? k_env_step_mf<16, 13, true, 7> : nullptr;
+#else
     if (tg) return (group == 16 && nv == 13) ? k_env_step_mf<16, 13, true, -1, true> : nullptr;          // the cupboard scene
     // the compiled reference configurations get instances with nv and ndense at compile time; anything else the generic ones
     if (group == 16) {
@@ -276,6 +280,7 @@ static persist_fn persist_kernel(int group, int nv, int ndense, bool tg = false)
     }
     if (nv == 25 && ndense == 7) return k_env_step_mf<32, 25, true, 7>;
     return k_env_step_mf<32, 32, false>;
+#endif
 }
 
 template <typename T>
@@ -658,6 +663,7 @@ static int batch_init(hsr_batch *b, const hsr_model *m, int n_envs) {
             for (int gi = d.nstatic_geom; gi < d.ngeom; gi++) if (gl[gi] == 0) ok = false;   // static geoms form a prefix of the geom list
         }
         if (b->persist_lds_bytes > 160 * 1024) ok = false;
+        if (!persist_kernel(b->group, d.nv, d.ndense, b->persist_tg)) ok = false;      // development builds carry one instance only
         b->persist_ok = ok;
         {   // trailing free bodies: link l owns exactly the dofs [nv - 6 (k + 1), nv - 6 k), lin then ang
             const int *dn = m->i32("link_dofnum"), *lf = m->i32("link_free"), *da = m->i32("link_dofadr"), *dt = m->i32("dof_type"), *dl = m->i32("dof_link");
