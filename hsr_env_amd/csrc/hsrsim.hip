@@ -19,6 +19,7 @@
 #include "solve_g.h"
 #include "solve_mf.h"
 #include "persist.h"
+#include "cfg_consts.h"
 
 static thread_local char g_err[512] = "";
 static int fail(int code, const char *fmt, const char *detail = "") {
@@ -262,23 +263,39 @@ __global__ void k_build_tables(DevModel m, DevState s) {
     }
 }
 
-// the persistent kernel instantiations: (lanes per env, compile-time bound on nv)
+// The persistent kernel instantiations.  Every reference configuration has an instance with ALL scalar model fields at compile time
+// (cfg_consts.h, generated from the committed blobs; chosen only when the loaded model matches the generated row value for value -
+// HSR_NO_CONST=1 never chooses them); any other model runs a generic instance (lanes per env, bound on nv).
 typedef void (*persist_fn)(const DevModel *, DevState, int, int, float, int, StepIO);
-static persist_fn persist_kernel(int group, int nv, int ndense, bool tg = false) {
+static int cfg_const_row(const DevModel &d) {
+    const char *nc = getenv("HSR_NO_CONST");
+    if (nc && strcmp(nc, "0") != 0) return -1;
+    int iv[20]; float fv[7];
+    cfg_const_values(d, iv, fv);
+    for (size_t r = 0; r < sizeof kCfgConsts / sizeof kCfgConsts[0]; r++)
+        if (memcmp(iv, kCfgConsts[r].i, sizeof iv) == 0 && memcmp(fv, kCfgConsts[r].f, sizeof fv) == 0) return (int)r;
+    return -1;
+}
+static persist_fn persist_kernel(const DevModel &d, int group, bool tg = false) {
+    const int row = cfg_const_row(d);
+    const int nv = d.nv;
 #ifdef HSR_DEV_CFG3
     // development builds (tools/build_variants.py): only the cfg3 instance is compiled - a sixth of the build time
-    return (!tg && group == 16 && nv == 13 && ndense == 7) ? k_env_step_mf<16, 13, true, 7> : nullptr;
+    return (!tg && row == 2) ? k_env_step_mf<16, 13, true, 7, false, DevModel_cfg3> : nullptr;
 #else
-    if (tg) return (group == 16 && nv == 13) ? k_env_step_mf<16, 13, true, -1, true> : nullptr;          // the cupboard scene
-    // the compiled reference configurations get instances with nv and ndense at compile time; anything else the generic ones
+    if (tg) return row == 4 ? k_env_step_mf<16, 13, true, -1, true, DevModel_cupboard> : nullptr;      // pair / geom tables in global memory (LDS budget)
+    switch (row) {
+    case 0: return k_env_step_mf<16, 2, true, 0, false, DevModel_cfg1>;            // two orthogonal slides
+    case 1: return k_env_step_mf<16, 8, true, 0, false, DevModel_cfg2>;            // the slides + one block
+    case 2: return k_env_step_mf<16, 13, true, 7, false, DevModel_cfg3>;           // arm + block
+    case 3: return k_env_step_mf<32, 25, true, 7, false, DevModel_cfg4>;           // arm + three blocks
+    case 4: return k_env_step_mf<16, 13, true, -1, false, DevModel_cupboard>;      // cupboard with its tables in LDS (HSR_TABLES_GLOBAL=0: 7 workgroups per CU)
+    default: break;
+    }
     if (group == 16) {
-        if (nv == 2 && ndense == 0) return k_env_step_mf<16, 2, true, 0>;            // cfg1: two orthogonal slides
-        if (nv == 8 && ndense == 0) return k_env_step_mf<16, 8, true, 0>;            // cfg2: the slides + one block
-        if (nv == 13 && ndense == 7) return k_env_step_mf<16, 13, true, 7>;          // cfg3: arm + block
-        if (nv == 13) return k_env_step_mf<16, 13, true>;                            // cupboard (ndense = nv) and others: ndense at run time
+        if (nv == 13) return k_env_step_mf<16, 13, true>;                            // ndense at run time
         return k_env_step_mf<16, 16, false>;
     }
-    if (nv == 25 && ndense == 7) return k_env_step_mf<32, 25, true, 7>;
     return k_env_step_mf<32, 32, false>;
 #endif
 }
@@ -637,12 +654,28 @@ static int batch_init(hsr_batch *b, const hsr_model *m, int n_envs) {
         }
     }
     {
+        {   // (before an instance is chosen: the constant instances are matched on nfb too)
+            // trailing free bodies: link l owns exactly the dofs [nv - 6 (k + 1), nv - 6 k), lin then ang
+            const int *dn = m->i32("link_dofnum"), *lf = m->i32("link_free"), *da = m->i32("link_dofadr"), *dt = m->i32("dof_type"), *dl = m->i32("dof_link");
+            int nfb = 0;
+            for (int k = 0; 6 * (k + 1) <= d.nv; k++) {
+                const int a0 = d.nv - 6 * (k + 1), l = dl[a0];
+                bool fb = l > 0 && lf[l] && da[l] == a0 && dn[l] == 6;
+                for (int j = 0; fb && j < 6; j++) fb = dl[a0 + j] == l && dt[a0 + j] == (j < 3 ? DOF_FREE_LIN : DOF_FREE_ANG);
+                if (!fb) break;
+                nfb++;
+            }
+            if (nfb * 28 * (64 / b->group) > 4 * 48) nfb = 0;                  // the per-body accumulators live in the box-box polygon scratch
+            const char *nf = getenv("HSR_NFB");                                // diagnostic: HSR_NFB=0 keeps the per-contact assembly
+            if (nf && atoi(nf) < nfb) nfb = atoi(nf) < 0 ? 0 : atoi(nf);
+            d.nfb = nfb;
+        }
         auto lds_total = [&](bool tg) { return (size_t)sizeof(float) * (b->group == 16 ? PersistLayout<16>(d.njmax, b->ds.kstride, d.npair_pad, d.nlink, d.ngeom, d.nstatic_geom, tg).total
                                                                                             : PersistLayout<32>(d.njmax, b->ds.kstride, d.npair_pad, d.nlink, d.ngeom, d.nstatic_geom, tg).total); };
         b->persist_lds_bytes = lds_total(false);
         {   // a model whose tables cost the eighth workgroup per CU (160 KB / 8 = 20480 B each, static LDS included) reads them from global memory
             hipFuncAttributes fa;
-            persist_fn f0 = persist_kernel(b->group, d.nv, d.ndense, false), f1 = persist_kernel(b->group, d.nv, d.ndense, true);
+            persist_fn f0 = persist_kernel(d, b->group, false), f1 = persist_kernel(d, b->group, true);
             if (f1 && hipFuncGetAttributes(&fa, (const void *)f0) == hipSuccess && b->persist_lds_bytes + fa.sharedSizeBytes > 20480
                 && hipFuncGetAttributes(&fa, (const void *)f1) == hipSuccess && lds_total(true) + fa.sharedSizeBytes <= 20480) {
                 b->persist_tg = true;
@@ -663,33 +696,19 @@ static int batch_init(hsr_batch *b, const hsr_model *m, int n_envs) {
             for (int gi = d.nstatic_geom; gi < d.ngeom; gi++) if (gl[gi] == 0) ok = false;   // static geoms form a prefix of the geom list
         }
         if (b->persist_lds_bytes > 160 * 1024) ok = false;
-        if (!persist_kernel(b->group, d.nv, d.ndense, b->persist_tg)) ok = false;      // development builds carry one instance only
+        if (!persist_kernel(d, b->group, b->persist_tg)) ok = false;      // development builds carry one instance only
         b->persist_ok = ok;
-        {   // trailing free bodies: link l owns exactly the dofs [nv - 6 (k + 1), nv - 6 k), lin then ang
-            const int *dn = m->i32("link_dofnum"), *lf = m->i32("link_free"), *da = m->i32("link_dofadr"), *dt = m->i32("dof_type"), *dl = m->i32("dof_link");
-            int nfb = 0;
-            for (int k = 0; 6 * (k + 1) <= d.nv; k++) {
-                const int a0 = d.nv - 6 * (k + 1), l = dl[a0];
-                bool fb = l > 0 && lf[l] && da[l] == a0 && dn[l] == 6;
-                for (int j = 0; fb && j < 6; j++) fb = dl[a0 + j] == l && dt[a0 + j] == (j < 3 ? DOF_FREE_LIN : DOF_FREE_ANG);
-                if (!fb) break;
-                nfb++;
-            }
-            if (nfb * 28 * (64 / b->group) > 4 * 48) nfb = 0;                  // the per-body accumulators live in the box-box polygon scratch
-            const char *nf = getenv("HSR_NFB");                                // diagnostic: HSR_NFB=0 keeps the per-contact assembly
-            if (nf && atoi(nf) < nfb) nfb = atoi(nf) < 0 ? 0 : atoi(nf);
-            b->dm.nfb = ok ? nfb : 0;
-        }
+        if (!ok) d.nfb = 0;
         const char *pe = getenv("HSR_PERSIST");
         b->persist = ok && !(pe && strcmp(pe, "0") == 0);
         if (ok && b->persist_lds_bytes > 48 * 1024)
-            HIPCHK(hipFuncSetAttribute((const void *)persist_kernel(b->group, d.nv, d.ndense, b->persist_tg), hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->persist_lds_bytes));
+            HIPCHK(hipFuncSetAttribute((const void *)persist_kernel(d, b->group, b->persist_tg), hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->persist_lds_bytes));
     }
     if (getenv("HSR_DEBUG") && b->persist_ok) {
         int pb = -1;
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&pb, persist_kernel(b->group, d.nv, d.ndense, b->persist_tg), 64, b->persist_lds_bytes);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&pb, persist_kernel(d, b->group, b->persist_tg), 64, b->persist_lds_bytes);
         hipFuncAttributes fb;
-        if (hipFuncGetAttributes(&fb, (const void *)persist_kernel(b->group, d.nv, d.ndense, b->persist_tg)) == hipSuccess)
+        if (hipFuncGetAttributes(&fb, (const void *)persist_kernel(d, b->group, b->persist_tg)) == hipSuccess)
             fprintf(stderr, "[hsrsim] k_env_step_mf<%d>: regs %d, static LDS %zu, dyn LDS %zu, scratch %zu -> %d workgroups per CU\n", b->group, fb.numRegs, fb.sharedSizeBytes, b->persist_lds_bytes, fb.localSizeBytes, pb);
     }
     {
@@ -970,7 +989,7 @@ extern "C" int hsr_batch_step_dev(hsr_batch *b, const float *d_ctrl, int n_subst
         const StepIO io{d_ctrl, d_obs, d_reward, d_done, d_nsteps};
         hipEvent_t k0 = nullptr, k1 = nullptr;
         if (b->kernel_log) { hipEventCreate(&k0); hipEventCreate(&k1); hipEventRecord(k0, st); }
-        hipLaunchKernelGGL(persist_kernel(b->group, b->dm.nv, b->dm.ndense, b->persist_tg), dim3((N + epb - 1) / epb), dim3(64), b->persist_lds_bytes, st, (const DevModel *)b->d_dm, dsl, n_substeps, goal_body, geofence, (b->debug_store ? 1 : 0) | b->test_hooks, io);
+        hipLaunchKernelGGL(persist_kernel(b->dm, b->group, b->persist_tg), dim3((N + epb - 1) / epb), dim3(64), b->persist_lds_bytes, st, (const DevModel *)b->d_dm, dsl, n_substeps, goal_body, geofence, (b->debug_store ? 1 : 0) | b->test_hooks, io);
         if (b->kernel_log) { hipEventRecord(k1, st); b->klog.push_back({k0, k1}); }
         if (b->profiling) { hipEvent_t ev; hipEventCreate(&ev); hipEventRecord(ev, st); b->kev.push_back(ev); }   // slots 0,1 empty; slot 2 = the persistent kernel
     } else if (b->use_graph && !b->profiling && n_substeps > 0) {

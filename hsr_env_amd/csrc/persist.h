@@ -46,14 +46,17 @@ template <int G> struct PersistLayout {
 // EXACT: nv == NVT, known at compile time (the `j < nv` guards of the unrolled matrix loops fold away)
 // NDT (EXACT only, else -1): ndense at compile time - the dofs from NDT on never couple to another dof in M (free bodies)
 // TG: pair records / geom constants read from global memory instead of LDS (for models with many pairs: 8 workgroups per CU)
-template <int G, int NVT, bool EXACT, int NDT = -1, bool TG = false>
+// MT: DevModel, or a type derived from it whose static constexpr members HIDE the scalar fields of the model (sizes, solver
+// options) with the values of one compiled configuration (cfg_consts.h): `m.nlink` is then a literal, the LDS layout a set of
+// immediates, and no scalar load / SGPR is spent on any of them; hsr_batch_create checks the values against the loaded model
+template <int G, int NVT, bool EXACT, int NDT = -1, bool TG = false, class MT = DevModel>
 __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restrict__ mp, DevState s, int n_substeps, int goal_body, float geofence, int flags, StepIO io) {
     // the ~90 model fields stay in (constant-cached) memory and are read where they are used, instead of sitting in - and
     // spilling from - SGPRs for the whole launch
-    const DevModel &m = *mp;
+    const MT &m = *static_cast<const MT *>(mp);
     extern __shared__ __align__(16) float lds[];
     constexpr int EPB = 64 / G, NK = NVT, NDK = EXACT ? NDT : -1;
-    const PersistLayout<G> L(m.njmax, s.kstride, m.npair_pad, m.nlink, m.ngeom, m.nstatic_geom, TG);
+    const PersistLayout<G> L(m.njmax, (9 * (EXACT ? NVT : m.nv) + 15 * m.nlink + 15) & ~15, m.npair_pad, m.nlink, m.ngeom, m.nstatic_geom, TG);      // second argument = DevState::kstride
     const int tid0 = threadIdx.x;
     const int N = s.N, nv = EXACT ? NVT : m.nv, nq = m.nq, R = L.R, MS = L.MS;
     const int mode = 1, debug = 0;

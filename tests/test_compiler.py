@@ -73,3 +73,14 @@ def test_numpy_mass_matrix_is_spd(models):
     for m in models.values():
         M = hc.mass_matrix(m, m.qpos0)
         assert np.allclose(M, M.T) and np.linalg.eigvalsh(M).min() > 0
+
+
+def test_generated_kernel_constants_match_the_blobs():
+    """hsr_env_amd/csrc/cfg_consts.h (scalar model fields as compile-time constants of the persistent-kernel instances of the
+    reference configurations) is generated from the committed blobs: regenerating it must reproduce the committed file."""
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    r = subprocess.run([sys.executable, str(root / "tools" / "gen_cfg_consts.py"), "--check"], capture_output=True, text=True)
+    assert r.returncode == 0, "cfg_consts.h is stale: run python tools/gen_cfg_consts.py\n" + r.stderr

@@ -634,3 +634,25 @@ def test_step_outputs_written_by_the_persistent_kernel(models):
     assert 0 < outs[0][2].sum() < n, "the case needs both early exits and full env-steps"
     assert np.array_equal(outs[0][2], outs[1][2]) and np.array_equal(outs[0][3], outs[1][3])
     assert np.abs(outs[0][0] - outs[1][0]).max() < 1e-5
+
+
+@pytest.mark.parametrize("cfg", ["cfg2", "cfg3", "cfg4"])
+def test_constant_instances_equal_the_generic_ones(models, cfg, monkeypatch):
+    """The reference configurations run kernel instances whose scalar model fields are compile-time constants (cfg_consts.h);
+    HSR_NO_CONST=1 runs the same model through the generic instance (fields read from memory).  Same algorithm, same inputs: the
+    results agree to rounding (constant folding may evaluate a reciprocal exactly where the hardware instruction is 1 ulp off)."""
+    m = models[cfg]
+    n = 128
+    rng = np.random.default_rng(21)
+    q, v, ctrl = random_states(m, n, rng)
+    outs = []
+    for nc in ("0", "1"):
+        monkeypatch.setenv("HSR_NO_CONST", nc)
+        sim = hs.BatchSim(m, n)
+        assert sim.is_persistent()
+        sim.set_state(np.zeros(n), q, v)
+        outs.append(sim.step(ctrl, 20)[0].copy())
+        sim.close()
+    d = np.abs(outs[0] - outs[1])
+    print(f"{cfg}: constant vs generic instance after 20 substeps: max |d| = {d.max():.2e}, median = {np.median(d):.2e}")
+    assert np.percentile(d, 99) < 1e-4 and np.median(d) < 1e-6
