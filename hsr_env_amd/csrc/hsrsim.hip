@@ -244,6 +244,9 @@ struct hsr_batch {
     int last_launches[3] = {0, 0, 0};
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<hipEvent_t> kev;
+    int slots = 0;                 // workgroups of the persistent kernel the GPU holds at once (occupancy x compute units)
+    int queue = -1;                // work queue of the persistent kernel: -1 = automatic (on when there are more tasks than slots), 0 / 1 forced (HSR_QUEUE)
+    int queue_chunk = 20;          // substeps per round of the work queue (HSR_QUEUE_CHUNK)
     bool kernel_log = false;       // hsr_batch_set_profiling(b, 2): an event pair around every launch of the persistent kernel, no synchronisation
     std::vector<std::pair<hipEvent_t, hipEvent_t>> klog;
 };
@@ -276,6 +279,7 @@ static int cfg_const_row(const DevModel &d) {
         if (memcmp(iv, kCfgConsts[r].i, sizeof iv) == 0 && memcmp(fv, kCfgConsts[r].f, sizeof fv) == 0) return (int)r;
     return -1;
 }
+enum { QUEUE_ROUNDS = 64 };
 static persist_fn persist_kernel(const DevModel &d, int group, bool tg = false) {
     const int row = cfg_const_row(d);
     const int nv = d.nv;
@@ -632,6 +636,16 @@ static int batch_init(hsr_batch *b, const hsr_model *m, int n_envs) {
     if ((rc = dalloc(b, &s.capstat, 4))) return rc;
     if ((rc = dalloc(b, &s.trips, N))) return rc;
     if ((rc = dalloc(b, &b->d_slot_env, N + 64))) return rc;
+    {   // work queue of the persistent kernel: up to QUEUE_ROUNDS rounds of one ticket per task (a task = the envs of one workgroup)
+        const size_t tasks = (N + 1) / 2;
+        if ((rc = dalloc(b, &s.q_head, QUEUE_ROUNDS))) return rc;
+        if ((rc = dalloc(b, &s.q_wpos, QUEUE_ROUNDS))) return rc;
+        if ((rc = dalloc(b, &s.q_items, (size_t)QUEUE_ROUNDS * tasks))) return rc;
+        if ((rc = dalloc(b, &s.q_err, 1))) return rc;
+        s.q_chunk = 0;
+        const char *q = getenv("HSR_QUEUE"); if (q) b->queue = atoi(q) != 0;
+        const char *qc = getenv("HSR_QUEUE_CHUNK"); if (qc && atoi(qc) > 0) b->queue_chunk = atoi(qc);
+    }
     s.slot_env = nullptr;
     { const char *sc = getenv("HSR_SCHEDULE"); b->schedule = !(sc && strcmp(sc, "0") == 0); }        // on unless HSR_SCHEDULE=0
     // cooperative solver geometry: 16 lanes per env when nv <= 16, else 32
@@ -704,6 +718,12 @@ static int batch_init(hsr_batch *b, const hsr_model *m, int n_envs) {
         if (ok && b->persist_lds_bytes > 48 * 1024)
             HIPCHK(hipFuncSetAttribute((const void *)persist_kernel(d, b->group, b->persist_tg), hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->persist_lds_bytes));
     }
+    if (b->persist_ok) {
+        int pb = 0;
+        hipDeviceProp_t prop;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&pb, persist_kernel(d, b->group, b->persist_tg), 64, b->persist_lds_bytes) == hipSuccess && pb > 0
+            && hipGetDeviceProperties(&prop, b->device) == hipSuccess) b->slots = pb * prop.multiProcessorCount;
+    }
     if (getenv("HSR_DEBUG") && b->persist_ok) {
         int pb = -1;
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&pb, persist_kernel(d, b->group, b->persist_tg), 64, b->persist_lds_bytes);
@@ -749,7 +769,8 @@ extern "C" void hsr_batch_destroy(hsr_batch *b) {
 #define NULLCHK(b) do { if (!(b)) return fail(HSR_EINVAL, "null batch"); } while (0)
 extern "C" int hsr_batch_size(const hsr_batch *b) { NULLCHK(b); return b->N; }
 extern "C" void *hsr_batch_stream(const hsr_batch *b) { return b ? (void *)b->stream : nullptr; }
-extern "C" int hsr_batch_sync(hsr_batch *b) { NULLCHK(b); HIPCHK(hipSetDevice(b->device)); HIPCHK(hipStreamSynchronize(b->stream)); return HSR_OK; }
+static int queue_error(hsr_batch *b);
+extern "C" int hsr_batch_sync(hsr_batch *b) { NULLCHK(b); HIPCHK(hipSetDevice(b->device)); HIPCHK(hipStreamSynchronize(b->stream)); return queue_error(b); }
 extern "C" int hsr_batch_set_profiling(hsr_batch *b, int on) { NULLCHK(b); b->profiling = on == 1; b->kernel_log = on == 2; return HSR_OK; }
 // durations (ms) of the persistent-kernel launches logged since the last call (hsr_batch_set_profiling(b, 2)); synchronises the stream
 extern "C" int hsr_batch_kernel_times(hsr_batch *b, float *out_ms, int cap) {
@@ -784,6 +805,22 @@ extern "C" int hsr_batch_set_persistent(hsr_batch *b, int on) {
 extern "C" int hsr_batch_is_persistent(const hsr_batch *b) { NULLCHK(b); return b->persist ? 1 : 0; }
 extern "C" int hsr_batch_set_debug(hsr_batch *b, int on) { if (!b) return fail(HSR_EINVAL, "null batch"); b->debug_store = (on & 1) != 0; b->test_hooks = on & 6; return HSR_OK; }
 extern "C" int hsr_batch_set_schedule(hsr_batch *b, int on) { NULLCHK(b); b->schedule = on != 0; return HSR_OK; }
+extern "C" int hsr_batch_set_queue(hsr_batch *b, int mode, int chunk) {
+    NULLCHK(b);
+    if (mode < -1 || mode > 1 || chunk < 0) return fail(HSR_EINVAL, "hsr_batch_set_queue: mode -1 / 0 / 1, chunk >= 0");
+    b->queue = mode;
+    if (chunk > 0) b->queue_chunk = chunk;
+    return HSR_OK;
+}
+// the work queue's watchdog (persist.h: q_claim) tripped in some launch since the last check
+static int queue_error(hsr_batch *b) {
+    int err = 0;
+    if (b->ds.q_err && hipMemcpy(&err, b->ds.q_err, sizeof err, hipMemcpyDeviceToHost) == hipSuccess && err) {
+        hipMemset(b->ds.q_err, 0, sizeof err);
+        return fail(HSR_EDEVICE, "persistent kernel: a work-queue ticket was never served (launch drained by its watchdog)");
+    }
+    return HSR_OK;
+}
 extern "C" int hsr_batch_set_goals(hsr_batch *b, int n, const int *body_a, const int *body_b, const float *dist) {
     if (!b || n < 0 || n > 4 || (n > 0 && (!body_a || !body_b || !dist))) return fail(HSR_EINVAL, "hsr_batch_set_goals: 0..4 terms");
     for (int k = 0; k < n; k++)
@@ -930,6 +967,13 @@ extern "C" int hsr_batch_get_warmstart(hsr_batch *b, float *w) { NULLCHK(b); HIP
 // One workgroup sorts up to 8192 envs (bitonic, keys in LDS); larger batches are packed chunk by chunk.
 // Results do not depend on the packing: no value of an env is ever combined with another env's.
 enum { SCHED_CHUNK = 8192 };
+// round 0 of the work queue holds every task in packing order (hard ones first); the other rounds are empty
+__global__ void k_queue_init(DevState s, int T, int R) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < R) { s.q_head[i] = 0; s.q_wpos[i] = i == 0 ? T : 0; }
+    if (i == 0) *s.q_err = 0;
+    if (i < R * T) s.q_items[i] = i < T ? i : -1;
+}
 __global__ void __launch_bounds__(1024) k_schedule(DevState s, int epb, int *slot_env) {
     __shared__ unsigned key[SCHED_CHUNK];
     const int e0 = blockIdx.x * SCHED_CHUNK, n = min(SCHED_CHUNK, s.N - e0);
@@ -987,9 +1031,21 @@ extern "C" int hsr_batch_step_dev(hsr_batch *b, const float *d_ctrl, int n_subst
         DevState dsl = b->ds;
         dsl.slot_env = sched ? b->d_slot_env : nullptr;
         const StepIO io{d_ctrl, d_obs, d_reward, d_done, d_nsteps};
+        // more tasks than the GPU holds workgroups at once: persistent workgroups + the work queue (persist.h), else one task per workgroup
+        const int T = (N + epb - 1) / epb;
+        int chunk = b->queue_chunk;
+        while ((n_substeps + chunk - 1) / chunk > QUEUE_ROUNDS) chunk *= 2;
+        const bool qon = b->slots > 0 && n_substeps >= 2 * chunk && (b->queue == 1 || (b->queue < 0 && T > b->slots));
+        int grid = T;
+        if (qon) {
+            const int R = (n_substeps + chunk - 1) / chunk;
+            dsl.q_chunk = chunk;
+            grid = T < b->slots ? T : b->slots;
+            hipLaunchKernelGGL(k_queue_init, grid1((size_t)R * T), dim3(256), 0, st, dsl, T, R);
+        }
         hipEvent_t k0 = nullptr, k1 = nullptr;
         if (b->kernel_log) { hipEventCreate(&k0); hipEventCreate(&k1); hipEventRecord(k0, st); }
-        hipLaunchKernelGGL(persist_kernel(b->dm, b->group, b->persist_tg), dim3((N + epb - 1) / epb), dim3(64), b->persist_lds_bytes, st, (const DevModel *)b->d_dm, dsl, n_substeps, goal_body, geofence, (b->debug_store ? 1 : 0) | b->test_hooks, io);
+        hipLaunchKernelGGL(persist_kernel(b->dm, b->group, b->persist_tg), dim3(grid), dim3(64), b->persist_lds_bytes, st, (const DevModel *)b->d_dm, dsl, n_substeps, goal_body, geofence, (b->debug_store ? 1 : 0) | b->test_hooks, io);
         if (b->kernel_log) { hipEventRecord(k1, st); b->klog.push_back({k0, k1}); }
         if (b->profiling) { hipEvent_t ev; hipEventCreate(&ev); hipEventRecord(ev, st); b->kev.push_back(ev); }   // slots 0,1 empty; slot 2 = the persistent kernel
     } else if (b->use_graph && !b->profiling && n_substeps > 0) {
@@ -1048,7 +1104,7 @@ extern "C" int hsr_batch_step(hsr_batch *b, const float *ctrl, int n_substeps, i
     if (done) HIPCHK(hipMemcpyAsync(done, b->d_stage_u8, N, hipMemcpyDeviceToHost, b->stream));
     if (nsteps) HIPCHK(hipMemcpyAsync(nsteps, b->d_stage_i32, N * sizeof(int32_t), hipMemcpyDeviceToHost, b->stream));
     HIPCHK(hipStreamSynchronize(b->stream));
-    return HSR_OK;
+    return queue_error(b);
 }
 
 extern "C" int hsr_batch_body_xpos(hsr_batch *b, int body_id, float *out) { NULLCHK(b);

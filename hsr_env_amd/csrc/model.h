@@ -74,6 +74,9 @@ struct DevState {
     // wave packing of the persistent kernel: slot_env[workgroup * envs_per_workgroup + group] = env index or -1 (NULL: identity);
     // trips[e] = Newton iterations env e ran in the last substeps of its last launch (what the packing is derived from)
     int *slot_env, *trips;
+    // work queue of the persistent kernel (persist.h: q_claim / q_push); q_chunk = 0: off (one task per workgroup, the whole env-step)
+    int q_chunk;
+    int *q_head, *q_wpos, *q_items, *q_err;
     unsigned long long *capstat;     // [4] cap statistics (include/hsrsim.h: hsr_batch_cap_counts)
     unsigned long long *phase_cyc;   // diagnostic build only (HSR_PHASE_TIMING): per-phase cycle sums
 };

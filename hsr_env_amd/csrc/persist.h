@@ -42,6 +42,57 @@ template <int G> struct PersistLayout {
     }
 };
 
+// ---- work queue of the persistent kernel (DevState::q_*; hsr_batch_step_dev turns it on when there are more tasks than workgroups
+// the GPU holds at once, e.g. 4096 two-env tasks of cfg4 at 8192 envs on 2048 resident workgroups).  Static assignment makes such a
+// launch end with whatever hard task happened to start in the second dispatch round (cfg4: 63 ms for 36 ms of work per slot); and
+// hardness cannot be predicted.  So the env-step is cut into rounds of q_chunk substeps, round r holds one ticket per task,
+// and a workgroup always takes the next ticket of the LOWEST round that has one left: a task that is behind (a hard one) is picked up
+// the moment it finishes its previous round - it runs back to back, and everything else fills the machine around it.
+//   q_head[r]  tickets of round r handed out so far (atomic counter; ticket h >= T: none left in this round)
+//   q_wpos[r]  items of round r pushed so far;  q_items[r * T + i]: task id, -1 until pushed (round 0 is filled by the host)
+// Every task passes through every round exactly once, so every ticket < T is served eventually: its holder waits for the item
+// (the workgroup that runs the task's previous round is resident - tickets are only taken by running workgroups, lowest round first, so
+// no cycle of waiting workgroups can form).  State handover: release fence + item store by the producer, item load + acquire fence
+// by the consumer, both at agent scope (the eight XCDs have separate L2 caches).  A spin that exceeds its bound sets q_err and
+// leaves: the launch then drains instead of hanging.
+__device__ __forceinline__ bool q_claim(const DevState &s, int T, int R, int &rlo, int &task, int &round) {
+    int t = -1, r = rlo;
+    if (threadIdx.x == 0) {
+        int h = 0;
+        for (; r < R; r++) {
+            if (__hip_atomic_load(&s.q_head[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= T) continue;
+            h = __hip_atomic_fetch_add(&s.q_head[r], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (h < T) break;
+        }
+        if (r < R) {
+            const int *slot = s.q_items + (size_t)r * T + h;
+            int spins = 0;
+            while ((t = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < 0) {
+                __builtin_amdgcn_s_sleep(16);
+                if (++spins > (1 << 22) || __hip_atomic_load(s.q_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {      // seconds: something is broken
+                    __hip_atomic_store(s.q_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    t = -1; r = R;
+                    break;
+                }
+            }
+        }
+    }
+    t = __builtin_amdgcn_readfirstlane(t); r = __builtin_amdgcn_readfirstlane(r);
+    rlo = r;
+    if (t < 0) return false;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    task = t; round = r;
+    return true;
+}
+__device__ __forceinline__ void q_push(const DevState &s, int T, int task, int round, bool last) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");      // every lane: its state stores are visible before the item is
+    __builtin_amdgcn_wave_barrier();
+    if (threadIdx.x == 0 && !last) {
+        const int p = __hip_atomic_fetch_add(&s.q_wpos[round + 1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(s.q_items + (size_t)(round + 1) * T + p, task, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 // NVT: compile-time bound on nv (nv <= NVT <= G); the matrix loops of the solver run to NVT instead of G
 // EXACT: nv == NVT, known at compile time (the `j < nv` guards of the unrolled matrix loops fold away)
 // NDT (EXACT only, else -1): ndense at compile time - the dofs from NDT on never couple to another dof in M (free bodies)
@@ -64,12 +115,16 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
     const bool hook_jv_per_contact = flags & 2, hook_majorant = flags & 4;      // tests: force the J v per contact / the PSD-majorant Newton step
     int cap_con = 0, cap_row = 0, cap_item = 0, nsub_run = 0;      // cap statistics of this lane's env (lane c == 0 reports)
     int own_trips = 0;                                              // Newton iterations of this lane's env over its last (up to) 100 substeps
+    // A task = the envs of one lane-group set (EPB envs) over a run of substeps.  Without the work queue (s.q_chunk == 0) there is one
+    // task per workgroup: its blockIdx.x and the whole env-step.  With it (more tasks than resident workgroups: see q_claim) a
+    // workgroup takes (task, round) tickets until none is left; the env state travels through the state arrays in between.
+    int task = blockIdx.x, q_round = 0, q_rlo = 0;
     // everything derived from the lane id is declared through this macro: once for the prologue, once per substep from a
     // laundered copy of the lane id (so that LLVM does not hoist ~100 loop-invariant addresses out of the substep loop and
     // then spill them), once for the epilogue
 #define PERSIST_LANE_VIEW(TID)                                                                                              \
     const int tid = (TID), g = tid / G, c = tid % G;                                                                         \
-    const int e_raw = s.slot_env ? s.slot_env[blockIdx.x * EPB + g] : blockIdx.x * EPB + g;                                  \
+    const int e_raw = s.slot_env ? s.slot_env[task * EPB + g] : task * EPB + g;                                              \
     const bool in_range = e_raw >= 0 && e_raw < N;                                                                           \
     const int e = in_range ? e_raw : 0;                                                                                      \
     float *E = lds + (size_t)g * L.envf;                                                                                     \
@@ -84,6 +139,7 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
     (void)rD; (void)rAref; (void)rJar; (void)rJv; (void)rDw; (void)kLin; (void)kAnc; (void)lk; (void)pcnt; (void)M; (void)con; \
     (void)poseL; (void)recL; (void)qvelL; (void)poly; (void)isdof; (void)e; (void)in_range;
     int bad_acc = 0, trips_acc = 0;
+    (void)q_rlo;
     // every byte counts: cfg4's 20.6 KB per workgroup were 144 B above an eighth of the CU's LDS (7 instead of 8 workgroups per CU)
     __shared__ signed char sParent[32];
     int *sMask = reinterpret_cast<int *>(lds + L.oLinkTab);
@@ -99,7 +155,6 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
     __shared__ unsigned char sDofLink[32];
     __shared__ int sEnv[64 / G];                       // env index of every lane group of this workgroup (wave packing: DevState::slot_env)
     __shared__ int sTick[64 / G];                      // substeps every env of this workgroup has run since its batch was created (DevState::tick): stamps of the separation margins
-    if (tid0 % G == 0) { const int er = s.slot_env ? s.slot_env[blockIdx.x * EPB + tid0 / G] : blockIdx.x * EPB + tid0 / G; sEnv[tid0 / G] = (er >= 0 && er < N) ? er : 0; sTick[tid0 / G] = s.tick[(er >= 0 && er < N) ? er : 0]; }
     if (tid0 < nv) sDofLink[tid0] = (unsigned char)m.dof_link[tid0];
     if (tid0 < m.nlink) kin2_store(m, tid0, lds + L.oKin + KIN2_FLOATS * tid0);
     // geom cache: constants of every geom, placements of the static ones (world link: identity pose)
@@ -123,22 +178,11 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
         reinterpret_cast<unsigned *>(lds + L.oPair)[p] = pk;
     }
 
-    // ---------------- load the env state once; it lives in registers for the whole env-step
     float qpos_c = 0, qvel_c = 0, warm_c = 0;          // qpos_c: lane = qpos index; qvel_c / warm_c: lane = dof
     bool done;
     v3 goal;
     float time_e;
     int nsteps_e = 0;
-    {
-        PERSIST_LANE_VIEW(tid0)
-        // HSREnv.step begins with `ctrl[:] = action` and a fresh done flag (hsr/env.py:116,124): with the caller's arrays at hand
-        // (io.ctrl) the kernel does both itself instead of a k_begin_step launch in front of it
-        done = !in_range || (io.ctrl ? false : s.done[e] != 0);
-        if (c < nq) qpos_c = s.qpos[(size_t)c * N + e];
-        if (isdof) { qvel_c = s.qvel[(size_t)c * N + e]; warm_c = s.warm[(size_t)c * N + e]; }
-        goal = mk3(s.mocap[e], s.mocap[N + e], s.mocap[2 * N + e]);
-        time_e = s.time[e];
-    }
     // per-lane model constants of the solver: loaded once per launch (the registers are there since the exact-nv build)
     float my_ctrl = 0, damp_c = 0;
     int my_type = -1, my_qadr = 0, my_quat_lane = -1, my_limited = 0, my_act = -1;
@@ -155,8 +199,6 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
 #pragma unroll
             for (int j = 0; j < 5; j++) lim_si[j] = m.dof_solimp[5 * c + j];
             if (my_act >= 0) {
-                if (io.ctrl) { my_ctrl = in_range ? io.ctrl[(size_t)e * m.nu + my_act] : 0.f; if (in_range) s.ctrl[(size_t)my_act * N + e] = my_ctrl; }
-                else my_ctrl = s.ctrl[(size_t)my_act * N + e];
                 act_p[0] = m.act_kp[my_act]; act_p[1] = m.act_gear[my_act];
                 act_p[2] = m.act_ctrlrange[2 * my_act]; act_p[3] = m.act_ctrlrange[2 * my_act + 1];
                 act_p[4] = m.act_forcerange[2 * my_act]; act_p[5] = m.act_forcerange[2 * my_act + 1];
@@ -167,10 +209,36 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
     const v3 goal_off = goal_body >= 0 ? ld3(m.body_pos, goal_body) : mk3(0, 0, 0);
     PHASE_T0();
 
-    for (int sub = 0; sub < n_substeps; sub++) {
+  for (;;) {      // task loop (a single pass without the work queue)
+    if (s.q_chunk) {
+        if (!q_claim(s, (N + EPB - 1) / EPB, (n_substeps + s.q_chunk - 1) / s.q_chunk, q_rlo, task, q_round)) break;
+    }
+    const int sub0 = s.q_chunk ? q_round * s.q_chunk : 0, sub1 = s.q_chunk ? min(n_substeps, sub0 + s.q_chunk) : n_substeps;
+    const bool first_run = sub0 == 0, last_run = sub1 >= n_substeps;
+    const bool fresh = io.ctrl != nullptr && first_run;       // HSREnv.step begins here: ctrl[:] = action, a fresh done flag (hsr/env.py:116,124)
+    cap_con = cap_row = cap_item = nsub_run = own_trips = 0; bad_acc = trips_acc = 0; nsteps_e = 0;
+    // ---------------- load the env state; it lives in registers for the whole run of substeps
+    {
+        PERSIST_LANE_VIEW(tid0)
+        if (c == 0) { sEnv[g] = e; sTick[g] = s.tick[e]; }
+        done = !in_range || (fresh ? false : s.done[e] != 0);
+        qpos_c = 0; qvel_c = 0; warm_c = 0;
+        if (c < nq) qpos_c = s.qpos[(size_t)c * N + e];
+        if (isdof) { qvel_c = s.qvel[(size_t)c * N + e]; warm_c = s.warm[(size_t)c * N + e]; }
+        goal = mk3(s.mocap[e], s.mocap[N + e], s.mocap[2 * N + e]);
+        time_e = s.time[e];
+        if (isdof && my_act >= 0) {
+            // with the caller's arrays at hand (io.ctrl) the kernel reads the action itself instead of a k_begin_step launch in front of it
+            if (fresh) { my_ctrl = in_range ? io.ctrl[(size_t)e * m.nu + my_act] : 0.f; if (in_range) s.ctrl[(size_t)my_act * N + e] = my_ctrl; }
+            else my_ctrl = s.ctrl[(size_t)my_act * N + e];
+        }
+    }
+    wave_sync();
+
+    for (int sub = sub0; sub < sub1; sub++) {
         // a workgroup that carries a hard env (many Newton iterations per substep so far) sets the pace of the launch: it
         // gets issue priority over the wave it shares its SIMD with, which has slack
-        if (sub >= 4 && 2 * trips_acc > 5 * sub) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);      // A/B on the bench: +4 %
+        if (sub - sub0 >= 4 && 2 * trips_acc > 5 * (sub - sub0)) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);      // A/B on the bench: +4 %
         int tid_l = tid0;
         asm volatile("" : "+v"(tid_l));
         PERSIST_LANE_VIEW(tid_l)
@@ -532,37 +600,46 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
         }
     }
     // ---------------- write the state back (struct-of-arrays)
+    {
     PERSIST_LANE_VIEW(tid0)
-    if (in_range && (io.ctrl || !(s.done[e] != 0 && nsteps_e == 0))) {
+    const int was_done = in_range ? s.done[e] : 0;
+    if (in_range && (fresh || !(was_done != 0 && nsteps_e == 0))) {
         if (c < nq) s.qpos[(size_t)c * N + e] = qpos_c;
         if (isdof) { s.qvel[(size_t)c * N + e] = qvel_c; s.warm[(size_t)c * N + e] = warm_c; }
-        // a-5 observation = concat(qpos, qvel) (hsr/env.py:111-113), env-major, straight from the registers
-        if (io.obs) {
-            float *o = io.obs + (size_t)e * (nq + nv);
-            if (c < nq) o[c] = qpos_c;
-            if (isdof) o[nq + c] = qvel_c;
-        }
         const float bsum = gsum<G>((float)bad_acc);
         if (c == 0) {
             if (cap_con) atomicAdd(&s.capstat[0], (unsigned long long)cap_con);
             if (cap_row) atomicAdd(&s.capstat[1], (unsigned long long)cap_row);
             if (cap_item) atomicAdd(&s.capstat[2], (unsigned long long)cap_item);
             atomicAdd(&s.capstat[3], (unsigned long long)nsub_run);
-            s.trips[e] = own_trips;
+            // hardness of the env for the next packing: Newton iterations over the last (up to) 100 substeps of the env-step
+            s.trips[e] = (sub0 <= n_substeps - 100 || first_run) ? own_trips : s.trips[e] + own_trips;
             s.tick[e] = sTick[g];
             s.time[e] = time_e;
             if (bsum > 0) s.bad[e] = 1;
-            if (io.ctrl) {
-                s.nsteps[e] = nsteps_e; s.done[e] = done ? 1 : 0;
-                if (io.reward) io.reward[e] = done ? 1.f : 0.f;          // reward = float(success) (hsr/env.py:133)
-                if (io.done) io.done[e] = done ? 1 : 0;
-                if (io.nsteps) io.nsteps[e] = nsteps_e;
-            } else {
-                s.nsteps[e] = s.nsteps[e] + nsteps_e;
-                if (done) s.done[e] = 1;
-            }
+            s.nsteps[e] = (fresh ? 0 : s.nsteps[e]) + nsteps_e;
+            if (fresh) s.done[e] = done ? 1 : 0; else if (done) s.done[e] = 1;
         }
     }
+    // a-5 observation = concat(qpos, qvel) (hsr/env.py:111-113), reward = float(success) (hsr/env.py:133), env-major, straight from
+    // the registers, when the env-step is complete
+    if (in_range && io.ctrl && last_run) {
+        if (io.obs) {
+            float *o = io.obs + (size_t)e * (nq + nv);
+            if (c < nq) o[c] = qpos_c;
+            if (isdof) o[nq + c] = qvel_c;
+        }
+        if (c == 0) {
+            if (io.reward) io.reward[e] = done ? 1.f : 0.f;
+            if (io.done) io.done[e] = done ? 1 : 0;
+            if (io.nsteps) io.nsteps[e] = s.nsteps[e];
+        }
+    }
+    }
+    if (!s.q_chunk) break;
+    q_push(s, (N + EPB - 1) / EPB, task, q_round, last_run);
+  }
+    const int tid = tid0; (void)tid;
 #ifdef HSR_PHASE_TIMING
     wave_sync();
     dc_[1] = (unsigned long long)sDbg[0] | ((unsigned long long)sDbg[1] << 24) | ((unsigned long long)sDbg[2] << 48);

@@ -132,6 +132,12 @@ int hsr_batch_set_debug(hsr_batch *b, int on);
  * Newton iterations they needed at the end of their previous launch (hard envs one per wave, with the easiest as neighbours).
  * A pure scheduling decision: every env's result is bit-identical with it on or off. */
 int hsr_batch_set_schedule(hsr_batch *b, int on);
+/* Work queue of the persistent kernel.  When a batch has more tasks (groups of 4 or 2 envs) than the GPU holds workgroups at once
+ * (BASELINE configs 4 / 5: 4096 two-env tasks on 2048 resident workgroups), the env-step is cut into rounds of `chunk` substeps and
+ * persistent workgroups take (task, round) tickets, lowest round first, so a task that lags is always resumed at once and no
+ * second dispatch round starts a hard task late.  mode: -1 automatic (default; HSR_QUEUE overrides at creation), 0 off, 1 on whenever the env-step
+ * has at least two rounds; chunk: substeps per round (0 keeps it; default 20, HSR_QUEUE_CHUNK).  Scheduling only: results are bit-identical. */
+int hsr_batch_set_queue(hsr_batch *b, int mode, int chunk);
 /* How often the device buffer caps bit since the last call (the counters are cleared): out[0] = (env, substep) pairs that
  * dropped contacts beyond nconmax, out[1] = dropped constraint rows beyond njmax, out[2] = dropped narrowphase work items
  * beyond 64 per env, out[3] = (env, substep) pairs executed.  MuJoCo's own caps are nconmax=100 njmax=500

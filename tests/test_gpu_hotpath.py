@@ -656,3 +656,32 @@ def test_constant_instances_equal_the_generic_ones(models, cfg, monkeypatch):
     d = np.abs(outs[0] - outs[1])
     print(f"{cfg}: constant vs generic instance after 20 substeps: max |d| = {d.max():.2e}, median = {np.median(d):.2e}")
     assert np.percentile(d, 99) < 1e-4 and np.median(d) < 1e-6
+
+
+@pytest.mark.parametrize("cfg", ["cfg3", "cfg4"])
+def test_work_queue_never_changes_a_result(models, cfg):
+    """The work queue of the persistent kernel (rounds of a few substeps, workgroups taking (task, round) tickets; automatic when a batch
+    has more tasks than the GPU holds workgroups) only decides WHO runs a task WHEN: forced on for a small batch, with rounds of 7
+    substeps and an env-step that early exits for some envs, every output and the whole state are bit-identical to the single-pass
+    launch, and so is a second env-step from the handed-over state (margins, stamps and warm starts travel through global memory)."""
+    m = models[cfg]
+    n = 330
+    rng = np.random.default_rng(31)
+    q, v, ctrl = random_states(m, n, rng)
+    goal = np.tile([0.0, 0.0, 0.422], (n, 1)).astype(np.float32)
+    res = []
+    for mode in (0, 1):
+        sim = hs.BatchSim(m, n)
+        sim.set_queue(mode, 7)
+        sim.set_mocap(goal)
+        sim.set_state(np.zeros(n), q, v)
+        out = []
+        for k in range(2):
+            obs, rew, done, ns = sim.step(ctrl, 60, m.body_id("block0"), 0.1)
+            t, qq, vv = sim.get_state()
+            out += [obs, rew, done, ns, t, qq, vv, sim.get_warmstart()]
+        res.append(out)
+        sim.close()
+    assert 0 < res[0][2].sum() < n, "the case needs early exits and full env-steps"
+    for a, b in zip(*res):
+        assert np.array_equal(a, b)
