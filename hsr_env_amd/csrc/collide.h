@@ -242,11 +242,21 @@ template <int W> __device__ __forceinline__ void sup_merge(float &b, int &idx, f
     const bool take = pb > b || (pb == b && pi < idx);
     b = take ? pb : b; idx = take ? pi : idx;
 }
-template <int W = 1> __device__ __forceinline__ v3 support(const Geom &G, v3 dir) {
+// vid (optional): which vertex it was - mesh: its index; box: the three sign bits; 0xff for the shapes without vertices.  A vertex id
+// names the same material point of the geom on the next substep (support_vertex), which is what the portal warm start needs.
+__device__ __forceinline__ v3 support_vertex(const Geom &G, int vid) {
+    v3 loc;
+    if (G.type == GEOM_BOX) loc = mk3((vid & 1) ? G.size.x : -G.size.x, (vid & 2) ? G.size.y : -G.size.y, (vid & 4) ? G.size.z : -G.size.z);
+    else { const float4 w = G.verts[vid]; loc = mk3(w.x, w.y, w.z); }
+    return mulmv(G.mat, loc) + G.pos;
+}
+template <int W = 1> __device__ __forceinline__ v3 support(const Geom &G, v3 dir, int *vid = nullptr) {
     const v3 dl = mulmtv(G.mat, dir);
     v3 loc;
+    if (vid) *vid = 0xff;
     if (G.type == GEOM_BOX) {
         loc = mk3(dl.x > 0 ? G.size.x : -G.size.x, dl.y > 0 ? G.size.y : -G.size.y, dl.z > 0 ? G.size.z : -G.size.z);
+        if (vid) *vid = (dl.x > 0 ? 1 : 0) | (dl.y > 0 ? 2 : 0) | (dl.z > 0 ? 4 : 0);
     } else if (G.type == GEOM_CYLINDER) {
         const float r2 = dl.x * dl.x + dl.y * dl.y, ir = frsq(r2);
         if (r2 > HSR_MINVAL * HSR_MINVAL) { loc.x = dl.x * ir * G.size.x; loc.y = dl.y * ir * G.size.x; } else { loc.x = 0; loc.y = 0; }
@@ -278,6 +288,7 @@ template <int W = 1> __device__ __forceinline__ v3 support(const Geom &G, v3 dir
         if constexpr (W >= 16) sup_merge<W>(b, idx, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, b), 0x140, 0xf, 0xf, false)), __builtin_amdgcn_update_dpp(0, idx, 0x140, 0xf, 0xf, false));
         const float4 w = G.verts[G.nvert > 0 ? idx : 0];
         loc = mk3(w.x, w.y, w.z);
+        if (vid) *vid = G.nvert > 0 ? idx : 0;
       } else {
         float bA = -3.0e38f, bB = -3.0e38f;
         int iA = 0, iB = 1;
@@ -302,6 +313,7 @@ template <int W = 1> __device__ __forceinline__ v3 support(const Geom &G, v3 dir
         const int best = (bB > bA || (bB == bA && iB < iA)) ? iB : iA;
         const float4 w = G.verts[G.nvert > 0 ? best : 0];
         loc = mk3(w.x, w.y, w.z);
+        if (vid) *vid = G.nvert > 0 ? best : 0;
       }
     }
     return mulmv(G.mat, loc) + G.pos;
@@ -639,7 +651,7 @@ __device__ __forceinline__ int collide_box_box_w8(const Geom &G1, const Geom &G2
 }
 
 // --- convex-convex: Minkowski Portal Refinement (libccd ccdMPRPenetration as used by mjc_Convex)
-struct Sup { v3 v, v1, v2; };
+struct Sup { v3 v, v1, v2; int id; };      // id: vertex ids of the two shapes (support()), id1 | id2 << 8
 #ifdef HSR_PHASE_TIMING
 __device__ int g_dbg_nsup_lane;   // unused placeholder to keep the symbol table stable
 #define DBG_COUNT_SUPPORT(ctr) (ctr)++
@@ -648,8 +660,16 @@ __device__ int g_dbg_nsup_lane;   // unused placeholder to keep the symbol table
 #endif
 template <int W = 1> __device__ __forceinline__ Sup mpr_support(const Geom &G1, const Geom &G2, v3 dir) {
     Sup s;
+#ifndef HSR_MPR_COLD_ONLY
+    int i1, i2;
+    s.v1 = support<W>(G1, dir, &i1);
+    s.v2 = support<W>(G2, -dir, &i2);
+    s.id = i1 | (i2 << 8);
+#else
     s.v1 = support<W>(G1, dir);
     s.v2 = support<W>(G2, -dir);
+    s.id = 0;
+#endif
     s.v = s.v1 - s.v2;
     return s;
 }
@@ -691,7 +711,7 @@ __device__ __forceinline__ v3 portal_dir(const Sup &p1, const Sup &p2, const Sup
 // place the three portal points in a scratch array with dynamic indexing: every MPR step went through memory)
 __device__ __forceinline__ Sup selS(bool c, const Sup &a, const Sup &b) {
     Sup r;
-    r.v = sel3(c, a.v, b.v); r.v1 = sel3(c, a.v1, b.v1); r.v2 = sel3(c, a.v2, b.v2);
+    r.v = sel3(c, a.v, b.v); r.v1 = sel3(c, a.v1, b.v1); r.v2 = sel3(c, a.v2, b.v2); r.id = c ? a.id : b.id;
     return r;
 }
 __device__ __forceinline__ void expand_portal(const Sup &p0, Sup &p1, Sup &p2, Sup &p3, const Sup &v4) {
@@ -709,14 +729,33 @@ __device__ __forceinline__ bool reach_tol(const Sup &p1, const Sup &p2, const Su
 
 // returns true on penetration; otherwise `sep` is a proven separating direction of the Minkowski difference
 // (support(A-B, sep) . sep < 0) or zero when MPR gave up without one
-template <int W = 1> __device__ bool mpr_penetration(const Geom &G1, const Geom &G2, float tol, int maxit, float &depth, v3 &dirout, v3 &pos, v3 &sep, int &nsup) {
+// warm: in: the vertex ids of last substep's final portal of this pair (three Sup::id, 0 = none); out: this run's.
+// The same six material points, placed with the present poses, are a portal again whenever the origin ray still passes through their
+// triangle (checked; else the search starts from scratch): the refinement then confirms the face it ended on last time with one or
+// two support calls instead of rediscovering it with eight.
+template <int W = 1> __device__ bool mpr_penetration(const Geom &G1, const Geom &G2, float tol, int maxit, float &depth, v3 &dirout, v3 &pos, v3 &sep, int &nsup, int *warm = nullptr) {
     const float eps = HSR_EPS;
     Sup p0, p1, p2, p3, v4;
-    p0.v1 = G1.pos; p0.v2 = G2.pos; p0.v = p0.v1 - p0.v2;
+    p0.v1 = G1.pos; p0.v2 = G2.pos; p0.v = p0.v1 - p0.v2; p0.id = 0;
     if (fabsf(p0.v.x) < eps && fabsf(p0.v.y) < eps && fabsf(p0.v.z) < eps) p0.v.x += 1e-5f;
     v3 dir = normalized(-p0.v);
     sep = mk3(0, 0, 0);
     nsup = 0;
+    bool warm_ok = false;
+#ifndef HSR_MPR_COLD_ONLY
+    if (warm && warm[0] > 0) {
+        auto rebuild = [&](int id, Sup &p) { p.id = id; p.v1 = support_vertex(G1, id & 0xff); p.v2 = support_vertex(G2, (id >> 8) & 0xff); p.v = p.v1 - p.v2; };
+        rebuild(warm[0] - 1, p1); rebuild(warm[1] - 1, p2); rebuild(warm[2] - 1, p3);
+        // the ray from p0 through the origin crosses the triangle, with the winding the refinement expects (the three tests of the
+        // portal discovery below), by a clear margin
+        const float m1 = 1e-4f * norm(p0.v);
+        const float s13 = dot(cross(p1.v, p3.v), p0.v), s32 = dot(cross(p3.v, p2.v), p0.v), s21 = dot(cross(p2.v, p1.v), p0.v);
+        const float sc = fmaxf(fmaxf(dot(p1.v, p1.v), dot(p2.v, p2.v)), dot(p3.v, p3.v)) * m1;
+        warm_ok = s13 > sc && s32 > sc && s21 > sc;
+    }
+    if (warm) { warm[0] = warm[1] = warm[2] = 0; }
+#endif
+  if (!warm_ok) {
     p1 = mpr_support<W>(G1, G2, dir); nsup++;
     if (dot(p1.v, dir) < eps) { sep = dir; return false; }
     dir = cross(p0.v, p1.v);
@@ -746,6 +785,7 @@ template <int W = 1> __device__ bool mpr_penetration(const Geom &G1, const Geom 
         if (!(c1 || c2)) break;
         dir = normalized(cross(p1.v - p0.v, p2.v - p0.v));
     }
+  }
     for (int it = 0;; it++) {
         dir = portal_dir(p1, p2, p3);
         if (dot(dir, p1.v) >= -eps) break;
@@ -780,6 +820,11 @@ template <int W = 1> __device__ bool mpr_penetration(const Geom &G1, const Geom 
             }
             const float inv = 0.5f * frcp(sum);
             pos = (p0.v1 * b0 + p1.v1 * b1 + p2.v1 * b2 + p3.v1 * b3 + p0.v2 * b0 + p1.v2 * b1 + p2.v2 * b2 + p3.v2 * b3) * inv;
+#ifndef HSR_MPR_COLD_ONLY
+            // the portal this run ended on, for the next substep - only vertices carry over (mesh, box)
+            auto vertex_ids = [](int id) { return (id & 0xff) != 0xff && ((id >> 8) & 0xff) != 0xff; };
+            if (warm && vertex_ids(p1.id) && vertex_ids(p2.id) && vertex_ids(p3.id)) { warm[0] = p1.id + 1; warm[1] = p2.id + 1; warm[2] = p3.id + 1; }
+#endif
             return true;
         }
         expand_portal(p0, p1, p2, p3, v4);
@@ -927,12 +972,14 @@ __global__ void __launch_bounds__(64) k_narrow(DevModel m, DevState s) {
                 float *sx = s.sepax + (size_t)(4 * p) * N + e;          // rows 4 p .. 4 p + 2: direction; row 4 p + 3: margin cache of the persistent kernel
                 const v3 d = mk3(sx[0], sx[N], sx[2 * (size_t)N]);
                 bool still = false;
-                if (d.x != 0.f || d.y != 0.f || d.z != 0.f) still = dot(support(G1, d) - support(G2, -d), d) < -1e-7f;
+                const bool is_dir = sx[3 * (size_t)N] >= 0.f;          // -1: the rows hold the portal vertex ids of the persistent kernel's warm start, not a direction
+                if (is_dir && (d.x != 0.f || d.y != 0.f || d.z != 0.f)) still = dot(support(G1, d) - support(G2, -d), d) < -1e-7f;
                 if (!still) {
                     float depth; v3 dir, pos, sep;
                     int nsup = 0;
                     if (mpr_penetration(G1, G2, m.mpr_tolerance, m.mpr_iterations, depth, dir, pos, sep, nsup)) { out.add(pos, dir, -depth); sep = mk3(0, 0, 0); }
                     sx[0] = sep.x; sx[N] = sep.y; sx[2 * (size_t)N] = sep.z;
+                    if (!is_dir) sx[3 * (size_t)N] = 0.f;
 #ifdef HSR_PHASE_TIMING
                     atomicAdd(&s.phase_cyc[20], (unsigned long long)nsup); atomicMax(&s.phase_cyc[21], (unsigned long long)nsup); atomicAdd(&s.phase_cyc[22], 1ull);
                     if (nsup > 20) atomicAdd(&s.phase_cyc[24], 1ull);

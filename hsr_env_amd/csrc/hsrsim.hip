@@ -236,6 +236,7 @@ struct hsr_batch {
     bool persist_ok = false;       // the model fits the persistent kernel (lane maps, LDS, kinematic structure): set once at creation
     bool use_graph = true, profiling = false, debug_store = false;
     bool persist_tg = false;       // persistent kernel instance that reads its pair / geom tables from global memory (LDS budget)
+    bool mpr_warm = true;          // penetrating convex pairs start MPR from the portal of their previous substep (HSR_MPR_WARM=0 / hsr_batch_set_mpr_warm turn it off)
     int test_hooks = 0;            // hsr_batch_set_debug bits 1.. : force rarely taken solver branches (tests only)
     bool schedule = true;          // re-pack the envs over the waves of the persistent kernel before every launch (HSR_SCHEDULE=0 / hsr_batch_set_schedule turn it off)
     int *d_slot_env = nullptr;
@@ -405,7 +406,11 @@ __global__ void k_reset(DevModel m, DevState s, const uint8_t *mask, const float
     for (int i = 0; i < m.nu; i++) s.ctrl[(size_t)i * N + e] = 0;
     for (int k = 0; k < 3; k++) s.mocap[(size_t)k * N + e] = mocap ? mocap[(size_t)e * 3 + k] : 0.f;
     s.time[e] = 0; s.bad[e] = 0; s.nsteps[e] = 0;
-    for (int p = 0; p < m.npair; p++) s.sepax[(size_t)(4 * p + 3) * N + e] = 0.f;     // the geoms jumped: no separation margin is left
+    for (int p = 0; p < m.npair; p++) {      // the geoms jumped: no separation margin is left, and no portal of the previous substep (margin row -1: rows 0-2 hold its vertex ids)
+        float *mg = s.sepax + (size_t)(4 * p + 3) * N + e;
+        if (*mg < 0.f) { mg[-(ptrdiff_t)N] = 0.f; mg[-2 * (ptrdiff_t)N] = 0.f; mg[-3 * (ptrdiff_t)N] = 0.f; }
+        *mg = 0.f;
+    }
 }
 __global__ void k_body_xpos(DevModel m, DevState s, int body, float *out) {
     int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -644,6 +649,7 @@ static int batch_init(hsr_batch *b, const hsr_model *m, int n_envs) {
         if ((rc = dalloc(b, &s.q_err, 1))) return rc;
         s.q_chunk = 0;
         const char *q = getenv("HSR_QUEUE"); if (q) b->queue = atoi(q) != 0;
+        const char *mw = getenv("HSR_MPR_WARM"); if (mw) b->mpr_warm = atoi(mw) != 0;
         const char *qc = getenv("HSR_QUEUE_CHUNK"); if (qc && atoi(qc) > 0) b->queue_chunk = atoi(qc);
     }
     s.slot_env = nullptr;
@@ -790,7 +796,11 @@ extern "C" int hsr_batch_kernel_times(hsr_batch *b, float *out_ms, int cap) {
 extern "C" int hsr_batch_set_graph(hsr_batch *b, int on) { NULLCHK(b); b->use_graph = on != 0; return HSR_OK; }
 __global__ void k_clear_margins(DevState s) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < (size_t)s.npair_sep * s.N) s.sepax[(4 * (i / s.N) + 3) * s.N + i % s.N] = 0.f;
+    if (i < (size_t)s.npair_sep * s.N) {
+        float *mg = s.sepax + (4 * (i / s.N) + 3) * s.N + i % s.N;
+        if (*mg < 0.f) { mg[-(ptrdiff_t)s.N] = 0.f; mg[-2 * (ptrdiff_t)s.N] = 0.f; mg[-3 * (ptrdiff_t)s.N] = 0.f; }      // portal vertex ids, not a direction
+        *mg = 0.f;
+    }
 }
 static void clear_margins(hsr_batch *b) {
     hipLaunchKernelGGL(k_clear_margins, grid1((size_t)b->ds.npair_sep * b->N), dim3(256), 0, b->stream, b->ds);
@@ -805,6 +815,13 @@ extern "C" int hsr_batch_set_persistent(hsr_batch *b, int on) {
 extern "C" int hsr_batch_is_persistent(const hsr_batch *b) { NULLCHK(b); return b->persist ? 1 : 0; }
 extern "C" int hsr_batch_set_debug(hsr_batch *b, int on) { if (!b) return fail(HSR_EINVAL, "null batch"); b->debug_store = (on & 1) != 0; b->test_hooks = on & 6; return HSR_OK; }
 extern "C" int hsr_batch_set_schedule(hsr_batch *b, int on) { NULLCHK(b); b->schedule = on != 0; return HSR_OK; }
+extern "C" int hsr_batch_set_mpr_warm(hsr_batch *b, int on) {
+    NULLCHK(b);
+    HIPCHK(hipSetDevice(b->device));
+    if ((on != 0) != b->mpr_warm) clear_margins(b);
+    b->mpr_warm = on != 0;
+    return HSR_OK;
+}
 extern "C" int hsr_batch_set_queue(hsr_batch *b, int mode, int chunk) {
     NULLCHK(b);
     if (mode < -1 || mode > 1 || chunk < 0) return fail(HSR_EINVAL, "hsr_batch_set_queue: mode -1 / 0 / 1, chunk >= 0");
@@ -1045,7 +1062,7 @@ extern "C" int hsr_batch_step_dev(hsr_batch *b, const float *d_ctrl, int n_subst
         }
         hipEvent_t k0 = nullptr, k1 = nullptr;
         if (b->kernel_log) { hipEventCreate(&k0); hipEventCreate(&k1); hipEventRecord(k0, st); }
-        hipLaunchKernelGGL(persist_kernel(b->dm, b->group, b->persist_tg), dim3(grid), dim3(64), b->persist_lds_bytes, st, (const DevModel *)b->d_dm, dsl, n_substeps, goal_body, geofence, (b->debug_store ? 1 : 0) | b->test_hooks, io);
+        hipLaunchKernelGGL(persist_kernel(b->dm, b->group, b->persist_tg), dim3(grid), dim3(64), b->persist_lds_bytes, st, (const DevModel *)b->d_dm, dsl, n_substeps, goal_body, geofence, (b->debug_store ? 1 : 0) | b->test_hooks | (b->mpr_warm ? 0 : 8), io);
         if (b->kernel_log) { hipEventRecord(k1, st); b->klog.push_back({k0, k1}); }
         if (b->profiling) { hipEvent_t ev; hipEventCreate(&ev); hipEventRecord(ev, st); b->kev.push_back(ev); }   // slots 0,1 empty; slot 2 = the persistent kernel
     } else if (b->use_graph && !b->profiling && n_substeps > 0) {

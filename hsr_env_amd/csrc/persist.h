@@ -113,6 +113,7 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
     const int mode = 1, debug = 0;
     const bool dbg_store = flags & 1;          // introspection: contact counts / solver counters of each env's last substep go to global memory
     const bool hook_jv_per_contact = flags & 2, hook_majorant = flags & 4;      // tests: force the J v per contact / the PSD-majorant Newton step
+    const bool mpr_warm = !(flags & 8);       // the portal of a penetrating convex pair is carried to its next substep (hsr_batch_set_mpr_warm)
     int cap_con = 0, cap_row = 0, cap_item = 0, nsub_run = 0;      // cap statistics of this lane's env (lane c == 0 reports)
     int own_trips = 0;                                              // Newton iterations of this lane's env over its last (up to) 100 substeps
     // A task = the envs of one lane-group set (EPB envs) over a run of substeps.  Without the work queue (s.q_chunk == 0) there is one
@@ -465,11 +466,19 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
                             // (the env's substep count at the last visit) then differs from tick - 1 and the margin counts as 0.
                             PHASE_M(26);
                             float *sx = s.sepax + (size_t)(4 * (it2 & 0x3fff)) * N + sEnv[it2 >> 14];
-                            const v3 d = mk3(sx[0], sx[N], sx[2 * (size_t)N]);
+                            v3 d = mk3(sx[0], sx[N], sx[2 * (size_t)N]);
                             float mg = sx[3 * (size_t)N];
                             int *stampp = s.septick + (size_t)(it2 & 0x3fff) * N + sEnv[it2 >> 14];
                             const int tick_now = sTick[it2 >> 14];
-                            if (*stampp != tick_now - 1) mg = 0.f;
+                            const bool fresh_cache = *stampp == tick_now - 1;
+                            int wid[3] = {0, 0, 0};
+                            // a pair that penetrated on the previous substep left the vertex ids of its final portal instead of a
+                            // separating direction (margin row = -1): the portal warm start of mpr_penetration
+                            if (mg < 0.f) {
+                                if (fresh_cache && mpr_warm) { wid[0] = __float_as_int(d.x); wid[1] = __float_as_int(d.y); wid[2] = __float_as_int(d.z); }
+                                d = mk3(0, 0, 0); mg = 0.f;
+                            }
+                            if (!fresh_cache) mg = 0.f;
                             {
                                 const unsigned pk2 = sPair[it2 & 0x3fff];
                                 const float *Ei2 = lds + (size_t)(it2 >> 14) * L.envf;
@@ -490,7 +499,7 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
                             if (!still) {
                                 float depth; v3 dir, pos, sep;
                                 int nsup = 0;
-                                const bool hit = mpr_penetration<MW>(H1, H2, m.mpr_tolerance, m.mpr_iterations, depth, dir, pos, sep, nsup);
+                                const bool hit = mpr_penetration<MW>(H1, H2, m.mpr_tolerance, m.mpr_iterations, depth, dir, pos, sep, nsup, wid);
 #ifdef HSR_PHASE_TIMING
                                 if ((tid & (MW - 1)) == 0) { atomicAdd(&sDbg[0], nsup); atomicAdd(&sDbg[1], 1); atomicMax(&sDbg[2], nsup); }
 #endif
@@ -501,8 +510,10 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
                                 mg = 0.f;
                                 if ((tid & (MW - 1)) == 0) {
                                     if (hit) { o2.add(pos, dir, -depth); sep = mk3(0, 0, 0); }
+                                    if (hit && wid[0] > 0 && mpr_warm) sep = mk3(__int_as_float(wid[0]), __int_as_float(wid[1]), __int_as_float(wid[2]));
                                     sx[0] = sep.x; sx[N] = sep.y; sx[2 * (size_t)N] = sep.z;
                                 }
+                                if (hit && wid[0] > 0 && mpr_warm) mg = -1.f;
                             }
                             if ((tid & (MW - 1)) == 0) { sx[3 * (size_t)N] = mg; *stampp = tick_now; }
                             if ((tid & (MW - 1)) == 0) *cntp = (unsigned char)o2.cnt;

@@ -37,7 +37,7 @@ EXPORTS = [
     "hsr_batch_step_dev", "hsr_batch_body_xpos", "hsr_batch_bad_state", "hsr_batch_get_field",
     "hsr_batch_set_profiling", "hsr_batch_last_timing", "hsr_batch_set_graph", "hsr_batch_set_persistent", "hsr_batch_is_persistent",
     "hsr_batch_obs_openai", "hsr_batch_obs_openai_dev", "hsr_batch_set_debug", "hsr_batch_cap_counts", "hsr_batch_newton_trips", "hsr_batch_set_schedule", "hsr_batch_set_goals",
-    "hsr_batch_phase_cycles", "hsr_batch_block_times", "hsr_batch_kernel_times", "hsr_batch_set_queue",
+    "hsr_batch_phase_cycles", "hsr_batch_block_times", "hsr_batch_kernel_times", "hsr_batch_set_queue", "hsr_batch_set_mpr_warm",
 ]
 
 F_XPOS, F_XMAT, F_M, F_QACC, F_QACC_SMOOTH, F_QFRC_SMOOTH, F_QFRC_CONSTRAINT, F_NCON, F_NEFC, F_CONTACT, F_NITER = range(11)
@@ -89,6 +89,7 @@ def load_library():
     L.hsr_batch_last_timing.argtypes = [vp, fp, fp, C.POINTER(C.c_int)]
     L.hsr_batch_kernel_times.argtypes = [vp, fp, C.c_int]
     L.hsr_batch_set_queue.argtypes = [vp, C.c_int, C.c_int]
+    L.hsr_batch_set_mpr_warm.argtypes = [vp, C.c_int]
     L.hsr_batch_set_graph.argtypes = [vp, C.c_int]
     L.hsr_batch_set_persistent.argtypes = [vp, C.c_int]
     L.hsr_batch_is_persistent.argtypes = [vp]
@@ -250,6 +251,10 @@ class BatchSim:
     def set_profiling(self, on):
         """True / 1: time the next step (synchronises); 2: log every launch of the persistent kernel (no synchronisation)."""
         _check(self._L, self._L.hsr_batch_set_profiling(self._b, int(on)))
+
+    def set_mpr_warm(self, on: bool):
+        """Portal warm start of the convex-pair narrowphase (include/hsrsim.h: hsr_batch_set_mpr_warm)."""
+        _check(self._L, self._L.hsr_batch_set_mpr_warm(self._b, int(on)))
 
     def set_queue(self, mode: int, chunk: int = 0):
         """Work queue of the persistent kernel: mode -1 automatic, 0 off, 1 on; chunk = substeps per round (0 keeps the current one)."""

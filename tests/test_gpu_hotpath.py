@@ -685,3 +685,69 @@ def test_work_queue_never_changes_a_result(models, cfg):
     assert 0 < res[0][2].sum() < n, "the case needs early exits and full env-steps"
     for a, b in zip(*res):
         assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("warm", [True, False])
+def test_pinched_block_contacts_follow_the_oracle(models, warm):
+    """The regime that sets the launch time: the block between the fingers (here: dropped into them, centimetres of overlap), two to
+    five mesh <-> box contacts (MPR) per env that persist, slide and break over the following substeps.  The persistent kernel carries
+    pair state from substep to substep there (warm = True, the default: the final portal of a penetrating pair is the starting portal of
+    its next run; separating axes and their margins otherwise).  After 1, 8 and 20 further substeps of its own the contacts of the
+    next forward pass are compared with the oracle's cold-started fp64 ones at the same state.
+    libccd measures the penetration to the final portal TRIANGLE; where the origin projects outside that triangle, depth and direction
+    depend on which triangle of the face the run ended on, and fp32 / fp64 / a warm start do not always end on the same one.  So in this
+    regime a few per cent of the envs differ beyond the stage tolerances (depth 1e-5, normal 2e-3, position 2e-4) in EITHER mode
+    (measured: cold 9 / 1 / 1, warm 13 / 4 / 0 of 96 envs at the three checkpoints, 317 / 170 / 94 convex contacts); the test bounds
+    both the share of such envs and the size of the differences, and requires identical contact counts."""
+    m = models["cfg3"]
+    n = 96
+    rng = np.random.default_rng(3)
+    q, v, ctrl = random_states(m, n, rng)
+    bl, br = m.body_id("hand_l_distal_link"), m.body_id("hand_r_distal_link")
+    a = m.free_joint_qadrs()[0]
+    fn, g1, g2 = m.arrays["pair_fn"], m.arrays["pair_geom1"], m.arrays["pair_geom2"]
+    convex = {(int(g1[p]), int(g2[p])) for p in range(m.npair) if fn[p] == 3}
+    for e in range(n):
+        o = OracleSim(m); o.qpos[:] = q[e]; o.forward()
+        q[e, a:a + 3] = 0.5 * (o.body_xpos(bl) + o.body_xpos(br)) + rng.uniform(-0.01, 0.01, 3)
+        quat = rng.normal(size=4); q[e, a + 3:a + 7] = quat / np.linalg.norm(quat)
+    v[:] = 0
+    sim = hs.BatchSim(m, n)
+    assert sim.is_persistent()
+    sim.set_mpr_warm(warm)
+    sim.set_debug(True)
+    sim.set_state(np.zeros(n), q, v)
+    nconvex_total = 0
+    for gap, share in ((1, 0.16), (8, 0.07), (20, 0.04)):
+        sim.step(ctrl, gap)
+        t1, q1, v1 = sim.get_state()
+        qs, vs = q1.astype(np.float64), v1.astype(np.float64)
+        sim.step(ctrl, 1)                                # its forward pass belongs to the state read back above
+        con = sim.get_field(hs.F_CONTACT)
+        edge, reasons, nconvex = 0, [], 0
+        for e in range(n):
+            o = OracleSim(m)
+            o.qpos[:] = qs[e]; o.qvel[:] = vs[e]; o.ctrl[:] = ctrl[e]
+            o.forward()
+            oc = o.contacts()
+            nconvex += sum((int(r[13]), int(r[14])) in convex for r in oc)
+            gc = con[e][con[e][:, 6] <= 0]
+            why = contact_mismatch(m, con[e], oc)
+            if why is not None:
+                shallow = (len(oc) and np.abs(oc[:, 12]).min() < 2e-6) or (len(gc) and np.abs(gc[:, 6]).min() < 2e-6)
+                if why.startswith("count") and shallow:
+                    edge += 1
+                else:
+                    reasons.append((e, why))
+        nconvex_total += nconvex
+        print(f"pinch (warm={warm}), after {gap} more substeps: {nconvex} convex contacts in the oracle, {edge} edge-of-existence envs, "
+              f"{len(reasons)} envs beyond the stage tolerances: {reasons[:12]}")
+        assert edge <= max(1, n // 50)
+        assert len(reasons) <= share * n, reasons
+        for e, why in reasons:
+            kind, size = why.split()[0], float(why.split()[1])
+            assert kind in ("depth", "normal", "position"), (e, why)          # never a different contact count
+            assert size < {"depth": 4e-3, "normal": 8e-2, "position": 1e-2}[kind], (e, why)
+    assert nconvex_total > 150, "the case must exercise mesh <-> box contacts"
+    assert not sim.bad_state()[1]
+    sim.close()
