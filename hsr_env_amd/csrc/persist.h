@@ -570,9 +570,9 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
         {
 #define SOLVE_STORE_DIAG dbg_store
 #define SOLVE_COUNT_CAPS 1
-#define PAIR_CNT(p) pcnt[p]
+#define PAIR_CNT8(p) (*reinterpret_cast<const unsigned long long *>(pcnt + (p)))
 #include "solve_body.inc"
-#undef PAIR_CNT
+#undef PAIR_CNT8
 #undef SOLVE_COUNT_CAPS
 #undef SOLVE_STORE_DIAG
             // ---------------- integrate (a-2.7) in registers; qpos is redistributed through LDS (lane = qpos index)

@@ -80,6 +80,14 @@ template <int G, int NK, int ND> __device__ __forceinline__ float chol_solve_tai
     return x;
 }
 
+// the contact counts of eight consecutive candidate pairs as one byte each (the chain keeps them as ints in global memory)
+__device__ __forceinline__ unsigned long long pair_cnt8_(const int *p) {
+    unsigned long long r = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) r |= (unsigned long long)(p[k] & 0xff) << (8 * k);
+    return r;
+}
+
 template <int G>
 __global__ void __launch_bounds__(64, 2) k_solve_mf(DevModel m, DevState s, int mode, int goal_body, float geofence, int debug) {
     extern __shared__ __align__(16) float lds[];
@@ -167,9 +175,9 @@ __global__ void __launch_bounds__(64, 2) k_solve_mf(DevModel m, DevState s, int 
     constexpr int nfb = 0;                 // the per-substep chain keeps the per-contact Hessian assembly (no scratch for the per-body one)
     float *fbK = nullptr;
 #define SOLVE_STORE_DIAG true
-#define PAIR_CNT(p) pair_cnt_[p]
+#define PAIR_CNT8(p) pair_cnt8_(pair_cnt_ + (p))
 #include "solve_body.inc"
-#undef PAIR_CNT
+#undef PAIR_CNT8
 #undef SOLVE_STORE_DIAG
     const float v1 = __shfl_down(vnew, 1, G), v2 = __shfl_down(vnew, 2, G);
     PHASE(16);
