@@ -811,7 +811,10 @@ def compile_model(dofs: Sequence[str] = ("slide_x", "slide_y"), n_blocks: int = 
     # oracle and the HIP path.  One lane group (16 or 32 lanes) serves an env, so caps are multiples of it.
     group = 16 if nv <= 16 else 32
     eff_nconmax = group
-    eff_njmax = {True: 48, False: 96}[nv <= 16]
+    # 32-lane models: 124 rows - measured on cfg4 (8192 envs x 300 env-steps of the bench: 7.4e8 env-substeps) 3.1e5 substeps wanted 97-104 rows,
+    # 8.9e3 105-112, 1.4e3 113-120, 24 121-128, 1 more: with 124 fewer than 4e-8 of the env-substeps drop a row (96 rows: 4.3e-4); 124 is what
+    # the 20 KB of LDS per workgroup hold once the pair / geom tables are read from global memory (persist.h: TG)
+    eff_njmax = {True: 48, False: 124}[nv <= 16]
     meta["xml_nconmax_njmax"] = [opt["nconmax"], opt["njmax"]]
     opt["nconmax"], opt["njmax"] = eff_nconmax, eff_njmax
 

@@ -288,7 +288,11 @@ static persist_fn persist_kernel(const DevModel &d, int group, bool tg = false) 
     // development builds (tools/build_variants.py): only the cfg3 instance is compiled - a sixth of the build time
     return (!tg && row == 2) ? k_env_step_mf<16, 13, true, 7, false, DevModel_cfg3> : nullptr;
 #else
-    if (tg) return row == 4 ? k_env_step_mf<16, 13, true, -1, true, DevModel_cupboard> : nullptr;      // pair / geom tables in global memory (LDS budget)
+    if (tg) {      // pair / geom tables in global memory (LDS budget: 8 workgroups per CU)
+        if (row == 4) return k_env_step_mf<16, 13, true, -1, true, DevModel_cupboard>;      // 274 candidate pairs
+        if (row == 3) return k_env_step_mf<32, 25, true, 7, true, DevModel_cfg4>;           // 124 constraint rows per env (compiler.py: eff_njmax)
+        return nullptr;
+    }
     switch (row) {
     case 0: return k_env_step_mf<16, 2, true, 0, false, DevModel_cfg1>;            // two orthogonal slides
     case 1: return k_env_step_mf<16, 8, true, 0, false, DevModel_cfg2>;            // the slides + one block
@@ -638,7 +642,7 @@ static int batch_init(hsr_batch *b, const hsr_model *m, int n_envs) {
     DA(ncon, 1) DA(nefc, 1) DA(niter, 1)
 #undef DA
     if ((rc = dalloc(b, &s.phase_cyc, 32 + 40 * 8192))) return rc;
-    if ((rc = dalloc(b, &s.capstat, 4))) return rc;
+    if ((rc = dalloc(b, &s.capstat, 12))) return rc;
     if ((rc = dalloc(b, &s.trips, N))) return rc;
     if ((rc = dalloc(b, &b->d_slot_env, N + 64))) return rc;
     {   // work queue of the persistent kernel: up to QUEUE_ROUNDS rounds of one ticket per task (a task = the envs of one workgroup)
@@ -856,6 +860,14 @@ extern "C" int hsr_batch_cap_counts(hsr_batch *b, unsigned long long *out) {
     HIPCHK(hipStreamSynchronize(b->stream));
     HIPCHK(hipMemcpy(out, b->ds.capstat, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     HIPCHK(hipMemset(b->ds.capstat, 0, 4 * sizeof(unsigned long long)));
+    return HSR_OK;
+}
+extern "C" int hsr_batch_cap_histogram(hsr_batch *b, unsigned long long *out) {
+    if (!b || !out) return fail(HSR_EINVAL, "null argument");
+    HIPCHK(hipSetDevice(b->device));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    HIPCHK(hipMemcpy(out, b->ds.capstat + 4, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemset(b->ds.capstat + 4, 0, 8 * sizeof(unsigned long long)));
     return HSR_OK;
 }
 

@@ -36,7 +36,7 @@ EXPORTS = [
     "hsr_batch_set_warmstart", "hsr_batch_get_warmstart", "hsr_batch_forward", "hsr_batch_step",
     "hsr_batch_step_dev", "hsr_batch_body_xpos", "hsr_batch_bad_state", "hsr_batch_get_field",
     "hsr_batch_set_profiling", "hsr_batch_last_timing", "hsr_batch_set_graph", "hsr_batch_set_persistent", "hsr_batch_is_persistent",
-    "hsr_batch_obs_openai", "hsr_batch_obs_openai_dev", "hsr_batch_set_debug", "hsr_batch_cap_counts", "hsr_batch_newton_trips", "hsr_batch_set_schedule", "hsr_batch_set_goals",
+    "hsr_batch_obs_openai", "hsr_batch_obs_openai_dev", "hsr_batch_set_debug", "hsr_batch_cap_counts", "hsr_batch_cap_histogram", "hsr_batch_newton_trips", "hsr_batch_set_schedule", "hsr_batch_set_goals",
     "hsr_batch_phase_cycles", "hsr_batch_block_times", "hsr_batch_kernel_times", "hsr_batch_set_queue", "hsr_batch_set_mpr_warm",
 ]
 
@@ -97,6 +97,7 @@ def load_library():
     L.hsr_batch_set_schedule.argtypes = [vp, C.c_int]
     L.hsr_batch_set_goals.argtypes = [vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), fp]
     L.hsr_batch_cap_counts.argtypes = [vp, C.POINTER(C.c_ulonglong)]
+    L.hsr_batch_cap_histogram.argtypes = [vp, C.POINTER(C.c_ulonglong)]
     L.hsr_batch_newton_trips.argtypes = [vp, C.POINTER(C.c_int32)]
     _lib = L
     return L
@@ -298,6 +299,12 @@ class BatchSim:
         out = (C.c_ulonglong * 4)()
         _check(self._L, self._L.hsr_batch_cap_counts(self._b, out))
         return tuple(int(x) for x in out)
+
+    def cap_histogram(self):
+        """Row-cap events by how many rows beyond njmax the env wanted (bins of 8 rows, last bin open); cleared by the call."""
+        out = (C.c_ulonglong * 8)()
+        _check(self._L, self._L.hsr_batch_cap_histogram(self._b, out))
+        return [int(x) for x in out]
 
     def newton_trips(self):
         """Newton iterations of every env over the last (up to) 100 substeps of the previous step() (persistent kernel)."""

@@ -150,6 +150,9 @@ int hsr_batch_set_queue(hsr_batch *b, int mode, int chunk);
  * beyond 64 per env, out[3] = (env, substep) pairs executed.  MuJoCo's own caps are nconmax=100 njmax=500
  * (hsr/models/world.xml:44); the compiled models carry smaller ones. */
 int hsr_batch_cap_counts(hsr_batch *b, unsigned long long *out /*[4]*/);
+/* of the row-cap events above: how many rows beyond njmax the env would have needed - out[k] counts the events with
+ * njmax + 8 k < rows wanted <= njmax + 8 (k + 1) (the last bin is open-ended); cleared by the call.  What the compiled njmax is sized by. */
+int hsr_batch_cap_histogram(hsr_batch *b, unsigned long long *out /*[8]*/);
 /* Newton iterations every env ran over the last (up to) 100 substeps of its previous env-step launch: the hardness measure
  * hsr_batch_set_schedule packs by (the solver's iteration count MuJoCo reports as mjData.solver_iter, summed). */
 int hsr_batch_newton_trips(hsr_batch *b, int32_t *out /*[n_envs]*/);
