@@ -946,6 +946,9 @@ TEST_CONFIGS = {
     # run time) - nv 11 in a 16-lane group, nv 23 in a 32-lane group
     "nv11": dict(dofs=["slide_x", "slide_y", "arm_lift_joint", "arm_flex_joint", "wrist_roll_joint"], n_blocks=1),
     "nv23": dict(dofs=["slide_x", "slide_y", "arm_lift_joint", "arm_flex_joint", "wrist_roll_joint"], n_blocks=3),
+    # no robot dof at all: the robot is scenery (15 static hulls + the wrist cylinder), the block the only body - thrown around it, it
+    # leaves and re-enters the cull ranges of the hulls (the separation-margin stamps of the convex pairs: tests/test_gpu_hotpath.py)
+    "static1": dict(dofs=[], n_blocks=1),
 }
 MODEL_DIR = Path(__file__).parent / "models"
 

@@ -113,6 +113,7 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
     const int mode = 1, debug = 0;
     const bool dbg_store = flags & 1;          // introspection: contact counts / solver counters of each env's last substep go to global memory
     const bool hook_jv_per_contact = flags & 2, hook_majorant = flags & 4;      // tests: force the J v per contact / the PSD-majorant Newton step
+    const bool hook_ignore_stamps = flags & 16;      // tests: trust a separation margin whatever its stamp (the behaviour before the stamps existed)
     const bool mpr_warm = !(flags & 8);       // the portal of a penetrating convex pair is carried to its next substep (hsr_batch_set_mpr_warm)
     int cap_con = 0, cap_row = 0, cap_item = 0, nsub_run = 0;      // cap statistics of this lane's env (lane c == 0 reports)
     int own_trips = 0;                                              // Newton iterations of this lane's env over its last (up to) 100 substeps
@@ -470,7 +471,7 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
                             float mg = sx[3 * (size_t)N];
                             int *stampp = s.septick + (size_t)(it2 & 0x3fff) * N + sEnv[it2 >> 14];
                             const int tick_now = sTick[it2 >> 14];
-                            const bool fresh_cache = *stampp == tick_now - 1;
+                            const bool fresh_cache = *stampp == tick_now - 1 || hook_ignore_stamps;
                             int wid[3] = {0, 0, 0};
                             // a pair that penetrated on the previous substep left the vertex ids of its final portal instead of a
                             // separating direction (margin row = -1): the portal warm start of mpr_penetration

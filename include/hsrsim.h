@@ -126,7 +126,9 @@ int hsr_batch_is_persistent(const hsr_batch *b);
  * per-pair contact counts (HSR_F_CONTACT), HSR_F_NCON / NEFC / NITER and HSR_F_QACC of every env's LAST substep (default off:
  * the fields then describe the last hsr_batch_forward).  Parity tests of the hot path's own narrowphase use it.
  * `on` is a bit mask: 1 = the above; 2 and 4 are test hooks that force rarely taken branches of the Newton solver of the persistent
- * kernel (2: J v per contact instead of per link; 4: every iteration takes the PSD-majorant Hessian) - same minimiser, other path. */
+ * kernel (2: J v per contact instead of per link; 4: every iteration takes the PSD-majorant Hessian) - same minimiser, other path;
+ * 16 makes the convex-pair section trust a cached separation margin whatever its stamp - the round-2 behaviour, kept so that the test of
+ * the stamps can show what they prevent. */
 int hsr_batch_set_debug(hsr_batch *b, int on);
 /* wave packing of the persistent kernel (default on; HSR_SCHEDULE=0 turns it off at creation): before every launch the envs are re-distributed over the waves by the
  * Newton iterations they needed at the end of their previous launch (hard envs one per wave, with the easiest as neighbours).
