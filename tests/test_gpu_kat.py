@@ -1,0 +1,107 @@
+"""GPU twins of the round-3 known-answer tests (tests/test_kat.py): the same closed forms evaluated through the C-ABI on the HIP path
+(fp32: the tolerances say what single precision leaves of them).  The oracle is not involved in the assertions."""
+import numpy as np
+import pytest
+
+from hsr_env_amd import sim as hs
+from test_kat import BLOCK_R, G, MU, MU_TORS, REST_DEPTH, cylinder_pressed_into_block, stacked_blocks
+
+pytestmark = pytest.mark.gpu
+
+
+def rest_state(m, n=8, steps=300):
+    """n copies of the model's initial state after `steps` substeps of the HIP path (the block settles on the pan)."""
+    sim = hs.BatchSim(m, n)
+    sim.step(np.zeros((n, m.nu), np.float32), steps)
+    t, q, v = sim.get_state()
+    return sim, q.astype(np.float64)
+
+
+def test_sliding_block_friction_ratio_and_slide_length(models):
+    """r3-1: total friction force = mu x total normal force, opposite to the velocity (forward pass, qfrc_constraint of the block's
+    translational dofs); a slide from v0 ends after v0^2 / (2 mu g) (3 %)."""
+    m = models["cfg2"]
+    sim, q = rest_state(m)
+    n, da, a = q.shape[0], m.nv - 6, m.free_joint_qadrs()[0]
+    v = np.zeros((n, m.nv))
+    ang = np.linspace(0.3, 5.9, n)
+    v[:, da] = np.cos(ang); v[:, da + 1] = np.sin(ang)
+    sim.set_state(np.zeros(n), q, v)                                     # forward pass with introspection
+    w = sim.get_field(hs.F_QFRC_CONSTRAINT)[:, da:da + 6]
+    assert (sim.get_field(hs.F_NCON) == 4).all() and (w[:, 2] > 0).all()
+    ft = np.hypot(w[:, 0], w[:, 1])
+    assert np.abs(ft / w[:, 2] - MU).max() < 2e-4
+    assert np.abs(w[:, 0] / ft + np.cos(ang)).max() < 3e-3 and np.abs(w[:, 1] / ft + np.sin(ang)).max() < 3e-3
+    for v0 in (1.0, 1.5):
+        q0 = q.copy(); q0[:, a] = -0.1
+        v = np.zeros((n, m.nv)); v[:, da] = v0
+        sim.set_state(np.zeros(n), q0, v)
+        sim.step(np.zeros((n, m.nu), np.float32), 400)
+        t, q1, v1 = sim.get_state()
+        assert np.abs(v1[:, da]).max() < 1e-4
+        assert np.abs((q1[:, a] + 0.1) / (v0 * v0 / (2 * MU * G)) - 1.0).max() < 0.03
+    sim.close()
+
+
+def test_spinning_block_torsional_rows(models):
+    """r3-2: braking torque of the spinning block = - F_n sqrt(mu^2 r^2 + mu_t^2) - the torsional row of condim 6 is 0.4 % of it."""
+    m = models["cfg2"]
+    sim, q = rest_state(m)
+    n, da = q.shape[0], m.nv - 6
+    v = np.zeros((n, m.nv))
+    v[:, da + 5] = np.array([15.0, -40.0, 5.0, 25.0, -8.0, 60.0, -20.0, 33.0])[:n]
+    sim.set_state(np.zeros(n), q, v)
+    w = sim.get_field(hs.F_QFRC_CONSTRAINT)[:, da:da + 6]
+    assert (sim.get_field(hs.F_NCON) == 4).all() and (w[:, 2] > 0).all()
+    want = -np.sign(v[:, da + 5]) * np.sqrt(MU ** 2 * BLOCK_R ** 2 + MU_TORS ** 2)
+    assert np.abs(w[:, 5] / w[:, 2] / want - 1.0).max() < 2e-4, (w[:, 5] / w[:, 2], want)
+    assert np.abs(np.abs(w[:, 5] / w[:, 2]) / (MU * BLOCK_R) - 1.0).min() > 2e-3            # distinguishable from sliding friction alone (4e-3)
+    assert np.abs(w[:, [0, 1, 3, 4]]).max() < 2e-3 * w[:, 2].min()
+    sim.close()
+
+
+def test_cylinder_pressed_into_block_mpr_depth(models):
+    """r3-3: MPR on the device (8-lane sub-group, fp32): depth = delta to 2e-6, normal = the cylinder axis to 1e-5."""
+    m = models["cfg3"]
+    deltas = [1e-3, 3e-3, 5e-4, 2e-3]
+    qs, axis = [], None
+    for d in deltas:
+        q, gi, bi, axis = cylinder_pressed_into_block(m, d)
+        qs.append(q)
+    n = len(deltas)
+    sim = hs.BatchSim(m, n)
+    sim.set_state(np.zeros(n), np.array(qs), np.zeros((n, m.nv)))
+    con = sim.get_field(hs.F_CONTACT)
+    p = [k for k in range(m.npair) if m.arrays["pair_geom1"][k] == gi and m.arrays["pair_geom2"][k] == bi][0]
+    slot = int(m.pair_slot[p])
+    for e, d in enumerate(deltas):
+        c = con[e, slot]
+        assert c[6] < 0, "the cylinder <-> block contact must exist"
+        assert abs(c[6] + d) < 2e-6 and np.abs(c[3:6] - axis).max() < 1e-5, (d, c)
+    sim.close()
+
+
+def test_stacked_blocks_static_equilibrium(models):
+    """r3-4: block 1 on block 0 (both constraints 2 x 2.4525e-6 m deep), block 2 alone (2.4525e-6 m), after 1500 substeps of the
+    persistent kernel; fp32 resolves the heights to 3e-8 m."""
+    m = models["cfg4"]
+    q, qa = stacked_blocks(m)
+    n = 4
+    sim = hs.BatchSim(m, n)
+    sim.set_state(np.zeros(n), np.tile(q, (n, 1)), np.zeros((n, m.nv)))
+    sim.set_debug(True)
+    for _ in range(5):
+        sim.step(np.tile(m.qpos0[:0], (n, 1)).reshape(n, 0) if m.nu == 0 else np.zeros((n, m.nu), np.float32), 300)
+    t, q1, v1 = sim.get_state()
+    assert np.abs(v1[:, m.nv - 18:]).max() < 1e-3
+    assert (sim.get_field(hs.F_NCON) == 12).all()
+    con = sim.get_field(hs.F_CONTACT)
+    g0 = m.ngeom - 3
+    want = {(1, g0): 2 * REST_DEPTH, (g0, g0 + 1): 2 * REST_DEPTH, (1, g0 + 2): REST_DEPTH}
+    for (ga, gb), d in want.items():
+        p = [k for k in range(m.npair) if m.arrays["pair_geom1"][k] == ga and m.arrays["pair_geom2"][k] == gb][0]
+        c = con[:, int(m.pair_slot[p]):int(m.pair_slot[p + 1])]
+        used = c[..., 6] <= 0
+        assert (used.sum(1) == 4).all()
+        assert np.abs(-c[..., 6][used] - d).max() < 4e-7, (ga, gb, c[..., 6][used])
+    sim.close()

@@ -241,3 +241,146 @@ def test_env_step_early_exit(models):
     assert (not done) and n == 300
     n, done = s.env_step(np.zeros(2), 7, -1, None, 0.0)
     assert (not done) and n == 7
+
+
+# ---- round 3: known answers for the regime that sets the launch time (condim-6 contacts in the middle zone of the elliptic cone, MPR
+# ---- depth, body-on-body contact); each has a twin through the C-ABI in tests/test_gpu_kat.py ---------------------------------------
+MU, MU_TORS = 1.0, 0.005                  # pan <-> block friction: tangential, torsional (world.xml default friction, hsr/util.py:120-125)
+BLOCK_R = float(np.hypot(0.05, 0.025))    # distance of the block's bottom corners from its vertical axis (hsr/util.py:120)
+REST_DEPTH = 2.4525e-6                    # m g / (4 D K d) of one block on the pan (test_block_rests_on_pan)
+
+
+def settled_block(m, x=0.0, steps=300):
+    s = OracleSim(m)
+    a = m.free_joint_qadrs()[0]
+    s.qpos[a] = x
+    for _ in range(steps):
+        s.step()
+    return s, a, m.nv - 6
+
+
+def block_wrench(s, da):
+    e = s.efc()
+    return (e["J"].T @ e["force"])[da:da + 6], e
+
+
+def sliding_state(m, vx=0.6, vy=-0.8):
+    s, a, da = settled_block(m)
+    q = s.qpos.copy()
+    t = OracleSim(m)
+    t.qpos[:] = q
+    t.qvel[da] = vx; t.qvel[da + 1] = vy
+    return t, a, da
+
+
+def test_sliding_block_friction_on_the_cone_boundary(models):
+    """KAT r3-1 (middle zone of the elliptic cone, impratio 2.5, world.xml:2): a block that slides on the pan without spinning has all
+    four corner contacts (condim 6) on the boundary of the friction cone WITH THE ORIGINAL coefficients - sum_j (f_j / mu_j)^2 = f_n^2
+    per contact whatever impratio does to the regularisers -, so the total friction force is mu x the total normal force, opposite to the
+    velocity; and over a whole slide the block stops after v0^2 / (2 mu g) (the contacts chatter - the block hops by millimetres -, the
+    impulse balance holds on average: 2 %)."""
+    m = models["cfg2"]
+    s, a, da = sliding_state(m)
+    s.forward()
+    w, e = block_wrench(s, da)
+    assert s.ncon == 4 and w[2] > 0
+    assert abs(np.hypot(w[0], w[1]) / w[2] - MU) < 1e-6                   # rolling rows (1e-4) take the rest
+    assert np.allclose(w[:2] / np.hypot(w[0], w[1]), [-0.6, 0.8], atol=2e-3)
+    fri = np.array([MU, MU, MU_TORS, 1e-4, 1e-4])
+    f = e["force"][-24:].reshape(4, 6)
+    for r in f[f[:, 0] > 1e-9]:
+        assert abs(np.sqrt(np.sum((r[1:] / fri) ** 2)) / r[0] - 1.0) < 1e-9
+    # the whole slide
+    for v0 in (1.0, 1.5):
+        s, a, da = settled_block(m, x=-0.1)
+        s.qvel[da] = v0
+        for _ in range(400):
+            s.step()
+        assert abs(s.qvel[da]) < 1e-6
+        assert abs((s.qpos[a] + 0.1) / (v0 * v0 / (2 * MU * G)) - 1.0) < 0.02
+
+
+def test_spinning_block_torsional_rows(models):
+    """KAT r3-2 (rows 3-5 of a condim-6 contact): the block spins about its vertical axis on the pan.  At each corner the sliding velocity
+    is w r and the spin w, the residuals of the tangential and the torsional row are in the ratio r : 1, the force on the cone boundary is
+    f_t = N mu^2 r / sqrt(mu^2 r^2 + mu_t^2), tau = N mu_t^2 / sqrt(...), and the total braking torque
+    tau_z = - F_n sqrt(mu^2 r^2 + mu_t^2)  (0.4 % more than sliding friction alone: the torsional row is visible)."""
+    m = models["cfg2"]
+    s, a, da = settled_block(m)
+    q = s.qpos.copy()
+    for w0 in (15.0, -40.0):
+        t = OracleSim(m)
+        t.qpos[:] = q
+        t.qvel[da + 5] = w0
+        t.forward()
+        w, e = block_wrench(t, da)
+        assert t.ncon == 4 and w[2] > 0
+        assert abs(w[5] / w[2] + np.sign(w0) * np.sqrt(MU ** 2 * BLOCK_R ** 2 + MU_TORS ** 2)) < 1e-10
+        assert abs(abs(w[5] / w[2]) - MU * BLOCK_R) > 1e-4                    # ... and not the value without the torsional row
+        assert np.abs(w[[0, 1, 3, 4]]).max() < 1e-9 * w[2]
+
+
+def cylinder_pressed_into_block(m, delta):
+    """State of cfg3 in which the flat end of the wrist cylinder (r = .017, half length .02, hsr.mjcf:149) is pressed `delta` deep
+    into the top face of the block, axis along the face normal.  Returns (qpos, cylinder geom id, block geom id, axis)."""
+    gi = [i for i, t in enumerate(m.arrays["geom_type"]) if t == hc.GEOM_CYLINDER][0]
+    bi = m.ngeom - 1
+    q = m.qpos0.copy()
+    xpos, xquat = hc.link_kinematics(m, q)
+    l = m.arrays["geom_link"][gi]
+    R = hc.quat_to_mat(xquat[l])
+    gp = xpos[l] + R @ m.arrays["geom_pos"][gi]
+    axis = (R @ hc.quat_to_mat(m.arrays["geom_quat"][gi]))[:, 2]
+    z = axis / np.linalg.norm(axis)
+    x = np.cross([0.0, 1.0, 0.0], z); x /= np.linalg.norm(x)
+    M = np.stack([x, np.cross(z, x), z], 1)
+    w = np.sqrt(1 + M[0, 0] + M[1, 1] + M[2, 2]) / 2
+    quat = np.array([w, (M[2, 1] - M[1, 2]) / (4 * w), (M[0, 2] - M[2, 0]) / (4 * w), (M[1, 0] - M[0, 1]) / (4 * w)])
+    a = m.free_joint_qadrs()[0]
+    q[a:a + 3] = gp + z * (0.02 + 0.017 - delta)
+    q[a + 3:a + 7] = quat
+    return q, gi, bi, z
+
+
+def test_cylinder_pressed_into_block_mpr_depth(models):
+    """KAT r3-3 (MPR, libccd's ccdMPRPenetration behind mjc_Convex): the flat end of the wrist cylinder pressed delta deep into a face of
+    the block, axis normal to the face: depth = delta, normal = the axis (from the cylinder to the block), for delta = 1 mm and 3 mm."""
+    m = models["cfg3"]
+    for delta in (1e-3, 3e-3):
+        q, gi, bi, axis = cylinder_pressed_into_block(m, delta)
+        s = OracleSim(m)
+        s.qpos[:] = q
+        s.forward()
+        c = [r for r in s.contacts() if int(r[13]) == gi and int(r[14]) == bi]
+        assert len(c) == 1
+        assert abs(c[0][12] + delta) < 1e-9 and np.allclose(c[0][3:6], axis, atol=1e-9)
+        assert np.linalg.norm(np.cross(c[0][0:3] - q[m.free_joint_qadrs()[0]:][:3], axis)) < 0.017 + 1e-9      # inside the cylinder's footprint
+
+
+def stacked_blocks(m):
+    qa = m.free_joint_qadrs()
+    q = m.qpos0.copy()
+    q[qa[0]:qa[0] + 3] = [0, 0, 0.422]; q[qa[1]:qa[1] + 3] = [0, 0, 0.422 + 0.034]; q[qa[2]:qa[2] + 3] = [0.0, 0.18, 0.422]
+    return q, qa
+
+
+def test_stacked_blocks_static_equilibrium(models):
+    """KAT r3-4 (contact between two moving bodies, static equilibrium): block 1 on block 0 on the pan, block 2 alone.  The four pan
+    contacts of block 0 carry 2 m g (4.905 N each); the four block-block contacts carry m g (2.4525 N each) through a constraint whose
+    regulariser sees BOTH bodies' inverse masses (R doubles, the same force needs twice the depth): both sets rest 2 x 2.4525e-6 m
+    deep, block 2 at 2.4525e-6 m."""
+    m = models["cfg4"]
+    q, qa = stacked_blocks(m)
+    s = OracleSim(m)
+    s.qpos[:] = q
+    for _ in range(1500):
+        s.step()
+    assert s.ncon == 12 and np.abs(s.qvel).max() < 1e-4
+    c = s.contacts()
+    g0 = m.ngeom - 3
+    depth = {(1, g0): 2 * REST_DEPTH, (g0, g0 + 1): 2 * REST_DEPTH, (1, g0 + 2): REST_DEPTH}
+    for r in c:
+        assert abs(-r[12] / depth[(int(r[13]), int(r[14]))] - 1.0) < 1e-6, r
+    assert abs(s.qpos[qa[0] + 2] - 0.422 + 2 * REST_DEPTH) < 1e-9 and abs(s.qpos[qa[1] + 2] - 0.456 + 4 * REST_DEPTH) < 1e-9
+    fn = np.sort(s.efc()["force"][-72:].reshape(12, 6)[:, 0])          # normal forces of the twelve condim-6 contacts
+    assert np.allclose(fn[:8], G / 4, rtol=1e-6) and np.allclose(fn[8:], G / 2, rtol=1e-6)      # m g / 4 (block 2, block 1 on 0), 2 m g / 4 (pan under the stack)
