@@ -89,6 +89,7 @@ typedef struct {
     double *qacc, *qfrc_constraint;
     int solver_niter, bad;
     double solver_cost;
+    int euler_rhs_macc;   /* test option (ho_set_euler_rhs): mj_Euler's damped solve takes M qacc as its right-hand side, as the HIP path does */
 } ho_data;
 
 /* ------------------------------------------------------------------ tiny vector helpers */
@@ -1066,7 +1067,14 @@ static void ho_euler(const ho_model *m, ho_data *d) {
     for (int k = 0; k < nv; k++) if (m->dof_damping[k] > 0) damped = 1;
     if (damped) {
         memcpy(A, d->M, sizeof(double)*(size_t)nv*(size_t)nv);
-        for (int k = 0; k < nv; k++) { A[k*nv+k] += h*m->dof_damping[k]; qacc[k] = d->qfrc_smooth[k] + d->qfrc_constraint[k]; }
+        /* MuJoCo: (M + h B) a = qfrc_smooth + qfrc_constraint.  With the option the right-hand side is M qacc - the same vector at the
+         * solver's fixed point (its gradient vanishes there), what the HIP path integrates (deviations): the parity tests
+         * report the difference from both forms */
+        for (int k = 0; k < nv; k++) {
+            A[k*nv+k] += h*m->dof_damping[k];
+            if (d->euler_rhs_macc) { double t = 0; for (int j = 0; j < nv; j++) t += d->M[k*nv+j]*d->qacc[j]; qacc[k] = t; }
+            else qacc[k] = d->qfrc_smooth[k] + d->qfrc_constraint[k];
+        }
         if (cholesky(La, A, nv) == 0) chol_solve(La, nv, qacc); else d->bad = 1;
     } else memcpy(qacc, d->qacc, sizeof(double)*(size_t)nv);
     for (int k = 0; k < nv; k++) d->qvel[k] += h*qacc[k];
@@ -1154,6 +1162,7 @@ int ho_ncon(const ho_data *d) { return d->ncon; }
 int ho_nefc(const ho_data *d) { return d->nefc; }
 int ho_bad(const ho_data *d) { return d->bad; }
 int ho_solver_niter(const ho_data *d) { return d->solver_niter; }
+void ho_set_euler_rhs(ho_data *d, int m_qacc) { d->euler_rhs_macc = m_qacc != 0; }
 /* contact i -> out[0:3] pos, [3:12] frame, [12] dist, [13] geom1, [14] geom2, [15] dim, [16] mu */
 void ho_contact_get(const ho_data *d, int i, double *out) {
     const ho_contact *c = d->contact + i;

@@ -46,6 +46,7 @@ def lib():
         for f in ("ncon", "nefc", "bad", "solver_niter"):
             getattr(L, "ho_" + f).restype = C.c_int; getattr(L, "ho_" + f).argtypes = [vp]
         L.ho_contact_get.argtypes = [vp, C.c_int, dp]
+        L.ho_set_euler_rhs.argtypes = [vp, C.c_int]; L.ho_set_euler_rhs.restype = None
         L.ho_batch_env_step.restype = C.c_int
         L.ho_batch_env_step.argtypes = [vp, C.c_int, dp, dp, dp, dp, dp, C.c_int, C.c_int, C.c_double, ip, C.c_int]
         _LIB = L
@@ -93,6 +94,10 @@ class OracleSim:
     def time(self): return float(self._time[0])
     @time.setter
     def time(self, v): self._time[0] = v
+
+    def set_euler_rhs(self, m_qacc: bool):
+        """mj_Euler's damped solve with M qacc as right-hand side (what the HIP path integrates) instead of MuJoCo's force form."""
+        self._L.ho_set_euler_rhs(self._d, int(m_qacc))
 
     def reset(self): self._L.ho_reset(self._m, self._d)
     def forward(self): self._L.ho_forward(self._m, self._d)

@@ -99,11 +99,20 @@ def test_forward_stages_match_oracle(models, cfg):
     sim.close()
 
 
+# envs of the single-substep test that may sit outside the tolerance BECAUSE a contact exists in one precision only (HIP contact count
+# != the oracle's; round 2 allowed 2 % of the envs): none has ever been observed on any configuration (rounds 2 and 3: 0 of 128 on
+# all five), so none is allowed; an observed one would have to be entered here with its explanation
+EXCUSED_ENVS = {"cfg1": 0, "cfg2": 0, "cfg3": 0, "cfg4": 0, "cupboard": 0}
+
+
 @pytest.mark.parametrize("cfg", ["cfg1", "cfg2", "cfg3", "cfg4", "cupboard"])
 def test_single_substep_matches_oracle(models, cfg):
-    """One substep from identical states through the persistent kernel: |dqpos| < 5e-6, |dqvel| < 1e-4 (1 + |qvel|).  An env
-    outside the tolerance must be EXPLAINED by a contact that exists in only one precision (HIP contact count of that substep
-    != the oracle's; at most 2 % of the envs): an unexplained env fails the test.  The counts are printed."""
+    """One substep from identical states through the persistent kernel: |dqpos| < 5e-6, |dqvel| < 1e-4 (1 + |qvel|) against the
+    oracle's mj_Euler in MuJoCo's form (right-hand side qfrc_smooth + qfrc_constraint).  The HIP path integrates M qacc instead
+    (identical at the solver's fixed point; DESIGN.md, deviations): the same substep is therefore also compared like for like, with the
+    oracle's Euler switched to M qacc, and both distances are printed - the tolerance must hold for BOTH.  An env outside it must be
+    EXPLAINED by a contact that exists in only one precision (HIP contact count of that substep != the oracle's), and how many such
+    envs a configuration may have is fixed per configuration (EXCUSED_ENVS: none on cfg1-3); an unexplained env fails the test."""
     m = models[cfg]
     n = 128
     rng = np.random.default_rng(11)
@@ -118,16 +127,27 @@ def test_single_substep_matches_oracle(models, cfg):
     ncon = sim.get_field(hs.F_NCON)
     assert (ns == 1).all() and not done.any()
     explained, unexplained = [], []
+    worst = {"force": [0.0, 0.0], "m_qacc": [0.0, 0.0]}
     for e in range(n):
-        o = pre[e]
-        o.step()
-        dq = np.abs(obs[e, :m.nq] - o.qpos).max()
-        dv = (np.abs(obs[e, m.nq:] - o.qvel) / (1 + np.abs(o.qvel))).max()
-        if not (dq < 5e-6 and dv < 1e-4):
-            (explained if int(ncon[e]) != o.ncon else unexplained).append((e, float(dq), float(dv), int(ncon[e]), o.ncon))
-    print(f"{cfg}: {len(explained)} envs outside tolerance with a different contact count, {len(unexplained)} unexplained")
+        for form in ("m_qacc", "force"):
+            o = OracleSim(m)
+            o.qpos[:] = q[e]; o.qvel[:] = v[e]; o.ctrl[:] = ctrl[e]; o.qacc_warmstart[:] = w[e]
+            o.set_euler_rhs(form == "m_qacc")
+            o.step()
+            dq = np.abs(obs[e, :m.nq] - o.qpos).max()
+            dv = (np.abs(obs[e, m.nq:] - o.qvel) / (1 + np.abs(o.qvel))).max()
+            same_contacts = int(ncon[e]) == o.ncon
+            if same_contacts:
+                worst[form][0] = max(worst[form][0], float(dq)); worst[form][1] = max(worst[form][1], float(dv))
+            if form == "force" and not (dq < 5e-6 and dv < 1e-4):
+                (unexplained if same_contacts else explained).append((e, float(dq), float(dv), int(ncon[e]), o.ncon))
+            if form == "m_qacc" and same_contacts:
+                assert dq < 5e-6 and dv < 1e-4, (e, dq, dv)
+    print(f"{cfg}: {len(explained)} of {n} envs outside tolerance with a different contact count (allowed {EXCUSED_ENVS[cfg]}), {len(unexplained)} unexplained; "
+          f"worst env with equal contacts: vs MuJoCo's Euler |dqpos| {worst['force'][0]:.2e} |dqvel|/(1+|qvel|) {worst['force'][1]:.2e}, "
+          f"vs Euler on M qacc {worst['m_qacc'][0]:.2e} {worst['m_qacc'][1]:.2e}")
     assert not unexplained, unexplained[:5]
-    assert len(explained) <= max(1, n // 50), explained[:5]
+    assert len(explained) <= EXCUSED_ENVS[cfg], explained[:5]
     assert not sim.bad_state()[1]
     sim.close()
 
