@@ -123,6 +123,29 @@ template <int G> __device__ __forceinline__ float gsum(float v) {
         return __builtin_bit_cast(float, (unsigned)sw[0]) + __builtin_bit_cast(float, (unsigned)sw[1]);
     }
 }
+// Six group sums at once, each delivered to ONE lane: after every halving step two half-reduced quantities share a register (the
+// upper half of the lanes carries the second), so the tree costs 6 + 3 + 2 + 1 DPP adds and 5 selects instead of 6 x 4 adds - and no
+// lane has to pick its value out of six afterwards.  Lane c of the group's first DPP row ends up with the sum of p[q] over the group,
+// q = gsum6_index(c), for c in {0, 8, 4, 12, 2, 10}; the other lanes hold duplicates or partial sums.
+__device__ __forceinline__ int gsum6_index(int c) { return ((c >> 3) & 1) + 2 * ((c >> 2) & 1) + 4 * ((c >> 1) & 1); }
+template <int G> __device__ __forceinline__ float gsum6_packed(const float (&p)[6], int c) {
+    float x[6];
+#pragma unroll
+    for (int q = 0; q < 6; q++) x[q] = p[q] + dpp_f<0x128, true>(p[q]);                       // lanes i and i + 8 (row_ror:8)
+    const bool h8 = c & 8, h4 = c & 4, h2 = c & 2;
+    float r0 = h8 ? x[1] : x[0], r1 = h8 ? x[3] : x[2], r2 = h8 ? x[5] : x[4];
+    r0 += dpp_f<0x141, true>(r0); r1 += dpp_f<0x141, true>(r1); r2 += dpp_f<0x141, true>(r2);      // lanes i and 7 - i of each half (row_half_mirror)
+    float z0 = h4 ? r1 : r0, z1 = r2;
+    z0 += dpp_f<0x1B, true>(z0); z1 += dpp_f<0x1B, true>(z1);                                   // lanes i and 3 - i of each quad (quad_perm 3 2 1 0)
+    float w = h2 ? z1 : z0;
+    w += dpp_f<0xB1, true>(w);                                                                   // neighbours (quad_perm 1 0 3 2)
+    if constexpr (G == 32) {
+        const unsigned u = __builtin_bit_cast(unsigned, w);
+        const auto sw = __builtin_amdgcn_permlane16_swap(u, u, false, false);                    // both DPP rows of the group
+        w = __builtin_bit_cast(float, (unsigned)sw[0]) + __builtin_bit_cast(float, (unsigned)sw[1]);
+    }
+    return w;
+}
 template <int G> __device__ __forceinline__ int gscan_incl(int v, int c) {
     v += dpp_i<0x111, true>(v); v += dpp_i<0x112, true>(v); v += dpp_i<0x114, true>(v); v += dpp_i<0x118, true>(v);      // inclusive scan inside the row
     if constexpr (G == 16) return v;
