@@ -229,8 +229,11 @@ template <int G, int NK, int ND> __device__ __forceinline__ bool chol_g_tail(flo
 }
 // elliptic cone at residual x: cost, gradient g, and the Hessian in the form
 //   H = diag(dw) + Dm gn gn^T - k3 u u^T      (zone 0 top: all zero; 1 bottom: dw = D; 2 middle)
+// The three cone functions take their six rows ZERO-PADDED: D[j] = x[j] = v[j] = 0 and fri[j - 1] = 0 for the rows j >= dim a contact
+// does not have (cone_rows / cone_fri in solve_body.inc) - every formula then yields 0 for them by itself, and no per-row test on dim
+// (six exec-mask branches per call) is needed.
 struct ConeOut { float cost, Dm, k3; int zone; float g[6], dw[6], gn[6], u[6]; };
-__device__ __forceinline__ void cone_eval2(int dim, float mu, const float *fri, const float *D, const float *x, ConeOut &o) {
+__device__ __forceinline__ void cone_eval2(int /*dim*/, float mu, const float *fri, const float *D, const float *x, ConeOut &o) {
     float U[6], T2 = 0;
 #pragma unroll
     for (int j = 0; j < 6; j++) { o.g[j] = 0; o.dw[j] = 0; o.gn[j] = 0; o.u[j] = 0; }
@@ -238,13 +241,13 @@ __device__ __forceinline__ void cone_eval2(int dim, float mu, const float *fri, 
     U[0] = x[0] * mu;
     const float Nn = U[0];
 #pragma unroll
-    for (int j = 1; j < 6; j++) { U[j] = (j < dim) ? x[j] * fri[j - 1] : 0.f; T2 += U[j] * U[j]; }
+    for (int j = 1; j < 6; j++) { U[j] = x[j] * fri[j - 1]; T2 += U[j] * U[j]; }
     const float T = fsqrt(T2);
     if (Nn >= mu * T || (T <= 0 && Nn >= 0)) return;
     if (mu * Nn + T <= 0 || (T <= 0 && Nn < 0)) {
         o.zone = 1;
 #pragma unroll
-        for (int j = 0; j < 6; j++) if (j < dim) { o.cost += 0.5f * D[j] * x[j] * x[j]; o.g[j] = D[j] * x[j]; o.dw[j] = D[j]; }
+        for (int j = 0; j < 6; j++) { o.cost += 0.5f * D[j] * x[j] * x[j]; o.g[j] = D[j] * x[j]; o.dw[j] = D[j]; }
         return;
     }
     o.zone = 2;
@@ -253,7 +256,7 @@ __device__ __forceinline__ void cone_eval2(int dim, float mu, const float *fri, 
     o.Dm = Dm; o.k3 = kappa * invT * frcp(T2);
     o.gn[0] = mu;
 #pragma unroll
-    for (int j = 1; j < 6; j++) if (j < dim) {
+    for (int j = 1; j < 6; j++) {
         o.gn[j] = -mu * U[j] * fri[j - 1] * invT;
         o.u[j] = fri[j - 1] * U[j];
         o.dw[j] = kappa * fri[j - 1] * fri[j - 1] * invT;
@@ -264,17 +267,17 @@ __device__ __forceinline__ void cone_eval2(int dim, float mu, const float *fri, 
 }
 
 // cost only (the warm-start comparison needs nothing else at the unconstrained point)
-__device__ __forceinline__ float cone_cost(int dim, float mu, const float *fri, const float *D, const float *x) {
+__device__ __forceinline__ float cone_cost(int /*dim*/, float mu, const float *fri, const float *D, const float *x) {
     const float Nn = x[0] * mu;
     float T2 = 0;
 #pragma unroll
-    for (int j = 1; j < 6; j++) { const float Uj = (j < dim) ? x[j] * fri[j - 1] : 0.f; T2 += Uj * Uj; }
+    for (int j = 1; j < 6; j++) { const float Uj = x[j] * fri[j - 1]; T2 += Uj * Uj; }
     const float T = fsqrt(T2);
     if (Nn >= mu * T || (T <= 0 && Nn >= 0)) return 0.f;
     if (mu * Nn + T <= 0 || (T <= 0 && Nn < 0)) {
         float cst = 0;
 #pragma unroll
-        for (int j = 0; j < 6; j++) if (j < dim) cst += 0.5f * D[j] * x[j] * x[j];
+        for (int j = 0; j < 6; j++) cst += 0.5f * D[j] * x[j] * x[j];
         return cst;
     }
     const float Dm = D[0] * frcp(mu * mu * (1 + mu * mu)), NT = Nn - mu * T;
@@ -282,20 +285,20 @@ __device__ __forceinline__ float cone_cost(int dim, float mu, const float *fri, 
 }
 // first and second derivative along v of the elliptic-cone cost at residual x (what the line search needs): the same
 // zones and formulas as cone_eval2 contracted with v analytically, d1 = g . v, d2 = v^T (diag(dw) + Dm gn gn^T - k3 u u^T) v
-__device__ __forceinline__ void cone_dd(int dim, float mu, const float *fri, const float *D, const float *x, const float *v, float &d1, float &d2) {
+__device__ __forceinline__ void cone_dd(int /*dim*/, float mu, const float *fri, const float *D, const float *x, const float *v, float &d1, float &d2) {
     d1 = 0; d2 = 0;
     const float Nn = x[0] * mu;
     float T2 = 0, S1 = 0, S2 = 0;
 #pragma unroll
     for (int j = 1; j < 6; j++) {
-        const float f = (j < dim) ? fri[j - 1] : 0.f, Uj = x[j] * f, fv = f * v[j];
+        const float f = fri[j - 1], Uj = x[j] * f, fv = f * v[j];
         T2 += Uj * Uj; S1 += Uj * fv; S2 += fv * fv;
     }
     const float T = fsqrt(T2);
     if (Nn >= mu * T || (T <= 0 && Nn >= 0)) return;
     if (mu * Nn + T <= 0 || (T <= 0 && Nn < 0)) {
 #pragma unroll
-        for (int j = 0; j < 6; j++) if (j < dim) { d1 += D[j] * x[j] * v[j]; d2 += D[j] * v[j] * v[j]; }
+        for (int j = 0; j < 6; j++) { d1 += D[j] * x[j] * v[j]; d2 += D[j] * v[j] * v[j]; }
         return;
     }
     const float Dm = D[0] * frcp(mu * mu * (1 + mu * mu)), NT = Nn - mu * T, invT = frcp(T);
