@@ -178,14 +178,19 @@ template <int G> __device__ __forceinline__ int glast(int v) {   // value of the
 // in-register cooperative Cholesky: lane c holds row c (entries k <= c) of an SPD matrix; on return row c of L in
 // row[0..c] (entries k > c are scratch) and invd = 1 / L[c][c].  Columns j >= ndense are known to have no
 // off-diagonal entries (block-diagonal tail of M): only their pivots are taken.
+// A failed pivot (not positive) is not tested for where it happens - the test and its select would sit in the dependent chain of every
+// step: rsq turns it into a NaN / infinity that reaches the invd of its own and of every later lane, and the group looks at all invd
+// once at the end.
+template <int G> __device__ __forceinline__ bool chol_pivots_ok(float invd) {
+    const bool badp = !(invd > 0.f && invd < 3.2e7f);          // rsq(1e-15) = 3.16e7: HSR_MINVAL as the smallest pivot accepted
+    return gmax<G>(badp ? 1 : 0) == 0;
+}
 template <int G, int NK = G> __device__ __forceinline__ bool chol_g(float (&row)[G], float &invd, int nv, int ndense, int c) {
-    bool ok = true;
     invd = 1.f;
     static_for<0, NK>([&](auto jc) {
         constexpr int j = decltype(jc)::value;
         if (j < nv) {
-            float ajj = gbcast_after_asm<G, j>(row[j]);
-            if (!(ajj >= HSR_MINVAL)) { ok = false; ajj = 1.f; }
+            const float ajj = gbcast_after_asm<G, j>(row[j]);
             const float inv = __builtin_amdgcn_rsqf(ajj);            // 1 ulp; the factor only shapes a Newton / Euler solve
             const float lcj = row[j] * inv;                          // lane j: ajj * rsq(ajj) = sqrt(ajj)
             if (c == j) invd = inv;
@@ -200,18 +205,16 @@ template <int G, int NK = G> __device__ __forceinline__ bool chol_g(float (&row)
             }
         }
     });
-    return ok;
+    return chol_pivots_ok<G>(invd);
 }
 // The same factorisation for a matrix whose columns j >= ND (compile time) have no off-diagonal entries at all - the inertia
 // matrix M and M + h D of a robot followed by free bodies with principal-axis inertia: ND pivot steps with updates of the first ND
 // rows only, and every tail lane takes the reciprocal root of its own diagonal entry (diag: lane c's M[c][c]; 1 for the padding lanes).
 template <int G, int NK, int ND> __device__ __forceinline__ bool chol_g_tail(float (&row)[G], float &invd, float diag, int c) {
-    bool ok = true;
     invd = 1.f;
     static_for<0, ND>([&](auto jc) {
         constexpr int j = decltype(jc)::value;
-        float ajj = gbcast_after_asm<G, j>(row[j]);
-        if (!(ajj >= HSR_MINVAL)) { ok = false; ajj = 1.f; }
+        const float ajj = gbcast_after_asm<G, j>(row[j]);
         const float inv = __builtin_amdgcn_rsqf(ajj);
         const float lcj = row[j] * inv;
         if (c == j) invd = inv;
@@ -220,12 +223,8 @@ template <int G, int NK, int ND> __device__ __forceinline__ bool chol_g_tail(flo
         const BcSrc<G> bl = bc_prepare<G>(lcj);
         static_for<j + 1, ND>([&](auto ic) { constexpr int i = decltype(ic)::value; fmac_bcast<G, i, bc_first<G, i, j + 1>()>(row[i], nl, bl); });
     });
-    if (c >= ND) {
-        float ajj = diag;
-        if (!(ajj >= HSR_MINVAL)) { ok = false; ajj = 1.f; }
-        invd = __builtin_amdgcn_rsqf(ajj);
-    }
-    return ok;
+    if (c >= ND) invd = __builtin_amdgcn_rsqf(diag);
+    return chol_pivots_ok<G>(invd);
 }
 // elliptic cone at residual x: cost, gradient g, and the Hessian in the form
 //   H = diag(dw) + Dm gn gn^T - k3 u u^T      (zone 0 top: all zero; 1 bottom: dw = D; 2 middle)

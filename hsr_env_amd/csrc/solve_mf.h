@@ -46,15 +46,23 @@ template <int G, int NK = G> __device__ __forceinline__ float chol_solve_mf(cons
             fmac_bcast<G, j, true>(sacc, nlo[j], bc_prepare<G>(t));   // sacc -= L[c][j] y_j
         }
     });
-    // L^T x = y: x_j = (y_j - sum_{i > j} L[i][j] x_i) / L[j][j]; the sum runs over lanes (nlo[j] is 0 for lanes i <= j)
+    // L^T x = y: x_j = (y_j - sum_{i > j} L[i][j] x_i) / L[j][j]; the sum runs over lanes (nlo[j] is 0 for lanes i <= j).  Two columns
+    // per step: the two group sums over the lanes solved so far run side by side, x_j follows, and column j - 1 only lacks the term of
+    // lane j itself, which lane j forms and broadcasts - one reduction latency per two columns of the dependent chain
     float x = 0.f;
-    static_for<0, NK>([&](auto jc) {
-        constexpr int j = NK - 1 - decltype(jc)::value;
-        if (j < nv) {
-            const float tot = gsum<G>(nlo[j] * x);
-            if (c == j) x = (y + tot) * invd;
+    static_for<0, NK / 2>([&](auto jc) {
+        constexpr int j = NK - 1 - 2 * decltype(jc)::value;           // columns j and j - 1
+        if (j - 1 < nv) {
+            const float A = gsum<G>(nlo[j] * x), B = gsum<G>(nlo[j - 1] * x);
+            const float xj = (j < nv) ? (y + A) * invd : 0.f;
+            if (c == j) x = xj;
+            const float t = gbcast<G, j>(nlo[j - 1] * xj);
+            if (c == j - 1) x = (y + B + t) * invd;
         }
     });
+    if constexpr (NK % 2 == 1) {
+        if (0 < nv) { const float tot = gsum<G>(nlo[0] * x); if (c == 0) x = (y + tot) * invd; }
+    }
     return x;
 }
 
