@@ -207,6 +207,33 @@ template <int G, int NK = G> __device__ __forceinline__ bool chol_g(float (&row)
     });
     return chol_pivots_ok<G>(invd);
 }
+// Factorisation and forward substitution in one sweep: step j also forms y_j = (b_j - sum_{k < j} L[j][k] y_k) / L[j][j] in lane j and
+// subtracts L[c][j] y_j from the running right-hand side of every lane c > j - one more multiply and DPP-FMA per step, hidden behind
+// the step's trailing updates, instead of a separate 13-step dependent chain afterwards.  Returns the pivot check; y is left in lane c.
+template <int G, int NK = G> __device__ __forceinline__ bool chol_g_fwd(float (&row)[G], float &invd, int nv, int c, float b, float &y) {
+    invd = 1.f;
+    float sacc = b;
+    y = 0.f;
+    static_for<0, NK>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        if (j < nv) {
+            const float ajj = gbcast_after_asm<G, j>(row[j]);
+            const float inv = __builtin_amdgcn_rsqf(ajj);
+            const float lcj = row[j] * inv;
+            const float t = sacc * inv;                               // lane j: y_j
+            if (c == j) { invd = inv; y = t; }
+            row[j] = lcj;
+            const float nl = -lcj;
+            const BcSrc<G> bl = bc_prepare<G>(lcj);
+            static_for<j + 1, NK>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                fmac_bcast<G, i, bc_first<G, i, j + 1>()>(row[i], nl, bl);
+            });
+            fmac_bcast<G, j, true>(sacc, c > j ? nl : 0.f, bc_prepare<G>(t));      // sacc -= L[c][j] y_j
+        }
+    });
+    return chol_pivots_ok<G>(invd);
+}
 // The same factorisation for a matrix whose columns j >= ND (compile time) have no off-diagonal entries at all - the inertia
 // matrix M and M + h D of a robot followed by free bodies with principal-axis inertia: ND pivot steps with updates of the first ND
 // rows only, and every tail lane takes the reciprocal root of its own diagonal entry (diag: lane c's M[c][c]; 1 for the padding lanes).

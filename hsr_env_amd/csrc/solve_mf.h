@@ -66,6 +66,28 @@ template <int G, int NK = G> __device__ __forceinline__ float chol_solve_mf(cons
     return x;
 }
 
+// back substitution alone (the forward half was done by chol_g_fwd): lane c holds y_c, the strictly lower part of row c of L and invd
+template <int G, int NK = G> __device__ __forceinline__ float chol_back_mf(const float (&row)[G], float invd, float y, int nv, int c) {
+    float nlo[G];
+#pragma unroll
+    for (int k = 0; k < NK; k++) nlo[k] = (k < c) ? -row[k] : 0.f;
+    float x = 0.f;
+    static_for<0, NK / 2>([&](auto jc) {
+        constexpr int j = NK - 1 - 2 * decltype(jc)::value;
+        if (j - 1 < nv) {
+            const float A = gsum<G>(nlo[j] * x), B = gsum<G>(nlo[j - 1] * x);
+            const float xj = (j < nv) ? (y + A) * invd : 0.f;
+            if (c == j) x = xj;
+            const float t = gbcast<G, j>(nlo[j - 1] * xj);
+            if (c == j - 1) x = (y + B + t) * invd;
+        }
+    });
+    if constexpr (NK % 2 == 1) {
+        if (0 < nv) { const float tot = gsum<G>(nlo[0] * x); if (c == 0) x = (y + tot) * invd; }
+    }
+    return x;
+}
+
 // ... and the two substitutions with such a factor (chol_g_tail): ND dependent steps each; a tail lane solves its own equation
 template <int G, int NK, int ND> __device__ __forceinline__ float chol_solve_tail(const float (&row)[G], float invd, float b, int c) {
     float nlo[ND > 0 ? ND : 1];
