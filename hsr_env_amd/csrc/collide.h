@@ -755,6 +755,7 @@ template <int W = 1> __device__ bool mpr_penetration(const Geom &G1, const Geom 
     }
     if (warm) { warm[0] = warm[1] = warm[2] = 0; }
 #endif
+  cold_start:
   if (!warm_ok) {
     p1 = mpr_support<W>(G1, G2, dir); nsup++;
     if (dot(p1.v, dir) < eps) { sep = dir; return false; }
@@ -801,6 +802,11 @@ template <int W = 1> __device__ bool mpr_penetration(const Geom &G1, const Geom 
             v3 pdir;
             bool interior;
             depth = fsqrt(point_tri_dist2(p1.v, p2.v, p3.v, pdir, interior));
+            // Where the origin projects into the final triangle, depth and direction are those of the face's plane - the same for every
+            // triangle of that face, however the run got there.  Where it does not, libccd measures to the triangle's edge and the answer
+            // depends on the triangle: a warm-started run then starts over from scratch, so that it ends where libccd's own search does
+            // (as far as single precision follows it).
+            if (!interior && warm_ok) { warm_ok = false; dir = normalized(-p0.v); goto cold_start; }
             if (interior) {
                 // the witness is the foot of the perpendicular: depth = |n . v1|, direction = +-n
                 const float dn = dot(dir, p1.v);
@@ -823,7 +829,8 @@ template <int W = 1> __device__ bool mpr_penetration(const Geom &G1, const Geom 
 #ifndef HSR_MPR_COLD_ONLY
             // the portal this run ended on, for the next substep - only vertices carry over (mesh, box)
             auto vertex_ids = [](int id) { return (id & 0xff) != 0xff && ((id >> 8) & 0xff) != 0xff; };
-            if (warm && vertex_ids(p1.id) && vertex_ids(p2.id) && vertex_ids(p3.id)) { warm[0] = p1.id + 1; warm[1] = p2.id + 1; warm[2] = p3.id + 1; }
+            // (only from a run whose witness was interior: one that ended on a triangle edge would be started over next time anyway)
+            if (warm && interior && vertex_ids(p1.id) && vertex_ids(p2.id) && vertex_ids(p3.id)) { warm[0] = p1.id + 1; warm[1] = p2.id + 1; warm[2] = p3.id + 1; }
 #endif
             return true;
         }

@@ -137,9 +137,11 @@ int hsr_batch_set_schedule(hsr_batch *b, int on);
 /* Convex pairs (mesh / cylinder vs box / mesh: MPR, libccd's ccdMPRPenetration behind mjc_Convex).  A pair that penetrates keeps the
  * vertex ids of the portal its run ended on; placed with the next substep's poses they are a portal again (checked: the origin ray
  * still crosses their triangle, else the run starts from scratch), so the refinement confirms the face it found last time with 2-3
- * support calls instead of rediscovering it with 8.  The refinement itself is libccd's; what can differ from a cold start is WHICH
- * triangle of a face the run ends on, and with it the witness point where libccd measures to the triangle's edge (DESIGN.md gives
- * the measured rates against the cold-started fp64 oracle).  Default on (HSR_MPR_WARM=0 at creation, or this call, turns it off). */
+ * support calls instead of rediscovering it with 8.  The refinement itself is libccd's.  Where the origin projects into the final
+ * triangle the result (the face's plane) does not depend on how the run got there; where it does not (libccd then measures to the
+ * triangle's edge) a warm-started run is repeated from scratch and nothing is kept for the next substep - the warm start is as close
+ * to the cold-started fp64 oracle as a cold fp32 run is (tests/test_gpu_hotpath.py::test_pinched_block_contacts_follow_the_oracle).
+ * Default on (HSR_MPR_WARM=0 at creation, or this call, turns it off). */
 int hsr_batch_set_mpr_warm(hsr_batch *b, int on);
 /* Work queue of the persistent kernel.  When a batch has more tasks (groups of 4 or 2 envs) than the GPU holds workgroups at once
  * (BASELINE configs 4 / 5: 4096 two-env tasks on 2048 resident workgroups), the env-step is cut into rounds of `chunk` substeps and

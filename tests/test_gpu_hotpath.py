@@ -698,10 +698,12 @@ def test_pinched_block_contacts_follow_the_oracle(models, warm):
     its next run; separating axes and their margins otherwise).  After 1, 8 and 20 further substeps of its own the contacts of the
     next forward pass are compared with the oracle's cold-started fp64 ones at the same state.
     libccd measures the penetration to the final portal TRIANGLE; where the origin projects outside that triangle, depth and direction
-    depend on which triangle of the face the run ended on, and fp32 / fp64 / a warm start do not always end on the same one.  So in this
-    regime a few per cent of the envs differ beyond the stage tolerances (depth 1e-5, normal 2e-3, position 2e-4) in EITHER mode
-    (measured: cold 9 / 1 / 1, warm 13 / 4 / 0 of 96 envs at the three checkpoints, 317 / 170 / 94 convex contacts); the test bounds
-    both the share of such envs and the size of the differences, and requires identical contact counts."""
+    depend on which triangle of the face the run ended on, and fp32 and fp64 do not always end on the same one.  So in this regime a few
+    per cent of the envs differ beyond the stage tolerances (depth 1e-5, normal 2e-3, position 2e-4) even from a cold start (measured:
+    8 / 1 / 1 of 96 envs at the three checkpoints, 317 / 170 / 92 convex contacts; differences up to 1.3e-3 in depth, 0.16 in the normal).
+    The warm start keeps to libccd's path where that matters - a warm run whose witness falls on a triangle edge is started over from
+    scratch, and only interior results seed the next run - and shows the same numbers (9 / 1 / 2).  The test bounds the share of such
+    envs and the size of the differences in both modes, and requires identical contact counts."""
     m = models["cfg3"]
     n = 96
     rng = np.random.default_rng(3)
@@ -721,7 +723,7 @@ def test_pinched_block_contacts_follow_the_oracle(models, warm):
     sim.set_debug(True)
     sim.set_state(np.zeros(n), q, v)
     nconvex_total = 0
-    for gap, share in ((1, 0.16), (8, 0.07), (20, 0.04)):
+    for gap, share in ((1, 0.13), (8, 0.04), (20, 0.04)):
         sim.step(ctrl, gap)
         t1, q1, v1 = sim.get_state()
         qs, vs = q1.astype(np.float64), v1.astype(np.float64)
@@ -750,7 +752,7 @@ def test_pinched_block_contacts_follow_the_oracle(models, warm):
         for e, why in reasons:
             kind, size = why.split()[0], float(why.split()[1])
             assert kind in ("depth", "normal", "position"), (e, why)          # never a different contact count
-            assert size < {"depth": 4e-3, "normal": 8e-2, "position": 1e-2}[kind], (e, why)
+            assert size < {"depth": 4e-3, "normal": 0.25, "position": 2e-2}[kind], (e, why)
     assert nconvex_total > 150, "the case must exercise mesh <-> box contacts"
     assert not sim.bad_state()[1]
     sim.close()
