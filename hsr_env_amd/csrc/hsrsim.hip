@@ -1,7 +1,9 @@
 // libhsrsim.so - host side of the C-ABI declared in include/hsrsim.h (gfx950 only).
 //
-// Owns: model tables on the device (fp32), per-batch SoA state, one HIP stream per batch, the
-// substep loop (3 kernels per substep, optionally replayed from a captured hipGraph).
+// Owns: model tables on the device (fp32), per-batch SoA state, one HIP stream per batch, and the launches: one persistent
+// kernel per env-step (persist.h: all substeps, ctrl in, obs / reward / done out; a work queue when the batch has more tasks than
+// resident workgroups), or - for models outside its lane maps, and as the cross-check of the tests - the per-substep chain
+// k_kinematics -> k_cull + k_narrow -> k_solve_mf, optionally replayed from a captured hipGraph.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdio.h>
@@ -880,7 +882,7 @@ extern "C" int hsr_batch_newton_trips(hsr_batch *b, int32_t *out) {
     return HSR_OK;
 }
 
-// one substep = 3 launches on the batch stream
+// one substep of the per-substep chain = 4 launches on the batch stream (the persistent kernel needs none of them)
 static void launch_substep(hsr_batch *b, int mode, int goal_body, float geofence, int debug, hipStream_t st, bool timed) {
     const int N = b->N;
     auto rec = [&](void) { if (timed) { hipEvent_t ev; hipEventCreate(&ev); hipEventRecord(ev, st); b->kev.push_back(ev); } };

@@ -5,14 +5,18 @@
 // counts between envs averages out over the substeps instead of stalling the whole GPU at every substep boundary
 // (with per-substep kernels the mean workgroup lifetime was 110 us but the kernel lasted 244 us).
 //
-// Phases per substep and lane roles:
-//   K  kinematics + RNE recursion: lane = link, one tree level at a time (kin_link_pose / kin_link_dyn, shared with
-//      k_kinematics); the per-link constants come from a 52-float LDS record built once per launch
-//   C  collision: lane = geom places every geom once (LDS); lane = candidate pair of its env does the bounding-sphere cull
-//      (pair records of eight chunks fetched together); survivors of ALL envs of the workgroup are compacted with wave ballots
-//      and box-culled one per lane; the items that remain run the narrowphase side by side - one lane per plane item, one
-//      8-lane sub-group per MPR or box-box item; contacts go to the env's fixed (pair, index) slots, counts stay in LDS
+// Phases per substep and lane roles (DESIGN.md has the cycle table):
+//   K  kinematics (kin2.h): A local transform of every link (lane = link, all at once), B world pose = product over the link's packed
+//      ancestor list, C dof axes / anchors / velocity-field increments (lane = dof), D spatial velocity and bias acceleration as fields
+//      accumulated over the chain dofs, E world inertia, com, RNE wrench; per-link constants from a 60-float LDS record built once per launch
+//   C  collision: lane = moving geom places it (LDS geom cache; static geoms once per launch); lane = eight consecutive candidate pairs does
+//      the bounding-sphere cull; survivors of ALL envs of the workgroup are compacted with wave ballots and box-culled one per lane; the
+//      items that remain run the narrowphase side by side - one lane per plane item, one 8-lane sub-group per MPR or box-box item
+//      (convex pairs: separating axis + stamped separation margin while apart, portal of the previous substep while penetrating);
+//      contacts go to the env's fixed (pair, index) slots, counts stay in LDS
 //   S  solve: the shared body solve_body.inc (lane = dof / contact / row), then the Euler update in registers
+// The env-step inputs and outputs of the caller (ctrl; obs, reward, done, nsteps) are read and written by this kernel (StepIO); with more
+// tasks than resident workgroups the launch runs as persistent workgroups over a work queue (q_claim / q_push below).
 #pragma once
 #include "collide.h"
 #include "kin2.h"
