@@ -1,7 +1,8 @@
 """Condense the rocprofv3 outputs of tools/profile_round.sh into profiles/: the kernel-trace stats CSV of the bench command and
 pmc_summary.json (HBM-side bytes per launch from FETCH_SIZE / WRITE_SIZE with the gfx950 correction of MI355X_MICROARCH.md -
 FETCH_SIZE counts half of a wide streaming read - and the SQ counters of the persistent kernel per wave and substep).
-usage: python tools/pmc_collect.py gpurun_out/prof_<tag> <tag> [substeps=300] [waves=2048]"""
+usage: python tools/pmc_collect.py gpurun_out/prof_<tag> <tag> [substeps=300] [waves=2048]
+The summary is rebuilt from scratch (kernels that no longer exist do not linger); its _note names the commit the numbers are from."""
 import csv, glob, json, shutil, sys
 from collections import defaultdict
 from pathlib import Path
@@ -28,7 +29,10 @@ stats = sorted(glob.glob(str(src / "trace" / "*" / "*kernel_stats.csv")), key=la
 if stats:
     shutil.copy(stats[-1], prof / f"{tag}_kernel_stats.csv")
 fetch, nf = counters("pmc_fetch"); write, nw = counters("pmc_write"); sq, ns = counters("pmc_sq")
-summary = json.loads((prof / "pmc_summary.json").read_text()) if (prof / "pmc_summary.json").exists() else {}
+import subprocess
+commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True, cwd=root).stdout.strip()
+dirty = bool(subprocess.run(["git", "status", "--porcelain", "--", "hsr_env_amd", "bench.py"], capture_output=True, text=True, cwd=root).stdout.strip())
+summary = {}
 for k in sorted(set(fetch) | set(write)):
     f = fetch[k].get("FETCH_SIZE", 0.0) / max(nf.get(k, 1), 1); w = write[k].get("WRITE_SIZE", 0.0) / max(nw.get(k, 1), 1)
     summary[k] = {"fetch_kb_per_launch": f, "write_kb_per_launch": w, "hbm_bytes_per_launch": (2 * f + w) * 1024, "launches": nf.get(k, 0)}
@@ -38,8 +42,8 @@ for k, v in sq.items():
         summary["_sq_per_wave_per_substep"] = {c: round(x / n, 1) for c, x in sorted(v.items())}
         summary["_sq_per_wave_per_substep"]["note"] = (f"{tag}: SQ counters of k_env_step_mf divided by (launches x {waves} waves x {nsub} substeps); "
                                                        "*_CYCLES / ACTIVE / WAIT in units of 4 clocks")
-summary["_note"] = (f"{tag}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_* in separate passes (with --kernel-trace only), python3 bench.py --steps 1 "
+summary["_note"] = (f"{tag}, commit {commit}{' + uncommitted changes' if dirty else ''}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_* in separate passes (with --kernel-trace only), python3 bench.py --steps 1 "
                     "--warmup 0 --no-cpu-baseline (cfg3, 8192 envs); bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 per the gfx950 correction of "
-                    "MI355X_MICROARCH.md; k_env_step_mf: one launch = 300 substeps of 8192 envs (algorithmic 630 MB); narrow accesses are uncalibrated")
+                    "MI355X_MICROARCH.md; k_env_step_mf: one launch = 300 substeps of 8192 envs (algorithmic 630 MB) including ctrl in and obs / reward / done out; narrow accesses are uncalibrated")
 (prof / "pmc_summary.json").write_text(json.dumps(summary, indent=1))
 print(json.dumps({k: summary[k] for k in summary if "env_step" in k or k.startswith("_sq")}, indent=1))
