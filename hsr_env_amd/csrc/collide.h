@@ -239,7 +239,8 @@ __device__ __forceinline__ Geom load_geom_v(const DevModel &m, View xpos, View x
 // (lane i takes vertices i, i + W, ...); a DPP butterfly picks the maximum, lowest index on ties - the same vertex the
 // sequential scan returns.
 template <int W> __device__ __forceinline__ void sup_merge(float &b, int &idx, float pb, int pi) {
-    const bool take = pb > b || (pb == b && pi < idx);
+    // bitwise, not short-circuit: `a || (b && c)` came back from the compiler as two nested exec-mask branches per merge step
+    const bool take = (pb > b) | ((pb == b) & (pi < idx));
     b = take ? pb : b; idx = take ? pi : idx;
 }
 // vid (optional): which vertex it was - mesh: its index; box: the three sign bits; 0xff for the shapes without vertices.  A vertex id
