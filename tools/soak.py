@@ -11,7 +11,7 @@ sim = BatchSim(m, n); sim.reset(qpos0=q0, mocap=goal); sim.cap_counts(); sim.cap
 dev = torch.device('cuda', 0)
 rng = np.random.Generator(np.random.Philox(key=[1, 0]))
 lo, hi = m.act_ctrlrange[:, 0].astype(np.float32), m.act_ctrlrange[:, 1].astype(np.float32)
-bid = m.body_id(m.block_body())
+bid = m.body_id(m.block_body()) if m.block_body() else -1
 d_done = torch.empty(n, dtype=torch.uint8, device=dev); d_ns = torch.empty(n, dtype=torch.int32, device=dev)
 t0 = time.time(); dones = 0
 for k in range(K):
