@@ -234,6 +234,30 @@ template <int G, int NK = G> __device__ __forceinline__ bool chol_g_fwd(float (&
     });
     return chol_pivots_ok<G>(invd);
 }
+// Accumulator of v_mfma_f32_16x16x1f32 (4 blocks of 16x16, K = 1; layouts measured with tools/micro/mfma_layout.hip): operand A / B of lane l
+// is row / column l % 16 of block l / 16; result register v of lane l is block v / 4, row 4 (l / 16) + v % 4, column l % 16.  add_rows:
+// the 4x4 transposition of (lane row, register group) - eight v_permlane32_swap, eight v_permlane16_swap - leaves block b in the 16
+// lanes of row b with register k = matrix row k, lane = column: lane c then holds sum_r A_r[k] B_r[c], k = 0..15.
+typedef float hess_v16f __attribute__((ext_vector_type(16)));
+struct HessAcc {
+    hess_v16f v;
+    __device__ __forceinline__ void clear() { v = hess_v16f{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; }
+    template <int NK, int G> __device__ __forceinline__ void add_rows(float (&row)[G]) {
+        unsigned r[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) { const float f = v[i]; r[i] = __float_as_uint(f); }      // (bit_cast of a vector element miscompiles: all lanes of element 0)
+#pragma unroll
+        for (int g = 0; g < 2; g++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) { const auto sw = __builtin_amdgcn_permlane32_swap(r[4 * g + i], r[4 * (g + 2) + i], false, false); r[4 * g + i] = sw[0]; r[4 * (g + 2) + i] = sw[1]; }
+#pragma unroll
+        for (int g = 0; g < 4; g += 2)
+#pragma unroll
+            for (int i = 0; i < 4; i++) { const auto sw = __builtin_amdgcn_permlane16_swap(r[4 * g + i], r[4 * (g + 1) + i], false, false); r[4 * g + i] = sw[0]; r[4 * (g + 1) + i] = sw[1]; }
+#pragma unroll
+        for (int k = 0; k < NK; k++) row[k] += __uint_as_float(r[k]);
+    }
+};
 // The same factorisation for a matrix whose columns j >= ND (compile time) have no off-diagonal entries at all - the inertia
 // matrix M and M + h D of a robot followed by free bodies with principal-axis inertia: ND pivot steps with updates of the first ND
 // rows only, and every tail lane takes the reciprocal root of its own diagonal entry (diag: lane c's M[c][c]; 1 for the padding lanes).
