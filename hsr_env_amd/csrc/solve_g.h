@@ -258,6 +258,27 @@ struct HessAcc {
         for (int k = 0; k < NK; k++) row[k] += __uint_as_float(r[k]);
     }
 };
+// The 32-lane twin: v_mfma_f32_32x32x1f32 (2 blocks of 32x32; tools/micro/mfma_layout32.hip): operand A / B of lane l is row / column l % 32 of
+// block l / 32; result register v of lane l is block v / 16, row 8 ((v % 16) / 4) + 4 (l / 32) + v % 4, column l % 32.  Sixteen
+// v_permlane32_swap (register t of the upper half <-> register 16 + t of the lower half) leave block b in the 32 lanes of half b, matrix
+// row i in register ((i / 4) % 2 ? 16 : 0) + 4 (i / 8) + i % 4.
+typedef float hess_v32f __attribute__((ext_vector_type(32)));
+struct HessAcc32 {
+    hess_v32f v;
+    __device__ __forceinline__ void clear() {
+#pragma unroll
+        for (int i = 0; i < 32; i++) v[i] = 0.f;
+    }
+    template <int NK, int G> __device__ __forceinline__ void add_rows(float (&row)[G]) {
+        unsigned r[32];
+#pragma unroll
+        for (int i = 0; i < 32; i++) { const float f = v[i]; r[i] = __float_as_uint(f); }
+#pragma unroll
+        for (int t = 0; t < 16; t++) { const auto sw = __builtin_amdgcn_permlane32_swap(r[t], r[16 + t], false, false); r[t] = sw[0]; r[16 + t] = sw[1]; }
+#pragma unroll
+        for (int k = 0; k < NK; k++) row[k] += __uint_as_float(r[((k / 4) % 2 ? 16 : 0) + 4 * (k / 8) + k % 4]);
+    }
+};
 // The same factorisation for a matrix whose columns j >= ND (compile time) have no off-diagonal entries at all - the inertia
 // matrix M and M + h D of a robot followed by free bodies with principal-axis inertia: ND pivot steps with updates of the first ND
 // rows only, and every tail lane takes the reciprocal root of its own diagonal entry (diag: lane c's M[c][c]; 1 for the padding lanes).
