@@ -158,11 +158,14 @@ def main():
     ap.add_argument("--config", default="cfg3")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--chunks", type=int, default=1, help="experiment: issue the env-step as this many launches of steps_per_action / chunks substeps")
     ap.add_argument("--no-persistent", action="store_true", help="per-substep kernels instead of the persistent env-step kernel")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="control-flow rehearsal of the N>1 path on a box with one GPU: every rank uses cuda:0 and the all-gather "
                          "goes through gloo on host copies (RCCL refuses two ranks on one device); the number it prints is not a result")
+    ap.add_argument("--env-offset", type=int, default=0, help="one-rank runs: global id of this process's first env (the shard a rank of a "
+                    "multi-GPU run would own); inputs are keyed by global env id, so the shard is reproduced env for env")
+    ap.add_argument("--dump-step", default=None, help="rank 0 writes obs | reward | done of the LAST timed env-step to this .npy: the gathered "
+                    "[global_envs, nq+nv+2] buffer for N > 1, the local one otherwise (tests compare the two)")
     ap.add_argument("--launch-check", action="store_true", help="print this rank's rendezvous environment and exit (no GPU touched): "
                     "exercises the self-launcher of --gpus N on a machine without GPUs")
     ap.add_argument("--fail-rank", type=int, default=-1, help="with --launch-check: this rank exits with code 3 at once and the others "
@@ -198,7 +201,7 @@ def main():
 
     m = load_config(args.config)
     n = args.envs_per_gpu
-    offset = rank * n
+    offset = rank * n + (args.env_offset if world == 1 else 0)
     K, W = args.steps, args.warmup
     total = K + W
     q0, goal = sample_inputs(m, n, 0, offset)
@@ -231,12 +234,13 @@ def main():
     torch.cuda.set_stream(ext)
     gather = hdist.StepGather(n, nobs, world, dev) if world > 1 else None
 
+    last_gathered = [None]
+
     def env_step(k):
-        for _ in range(args.chunks):
-            sim.step_dev(d_ctrl[k].data_ptr(), STEPS_PER_ACTION // args.chunks, bid, GEOFENCE, d_obs.data_ptr(), d_rew.data_ptr(),
-                         d_done[k].data_ptr(), d_ns[k].data_ptr())
+        sim.step_dev(d_ctrl[k].data_ptr(), STEPS_PER_ACTION, bid, GEOFENCE, d_obs.data_ptr(), d_rew.data_ptr(),
+                     d_done[k].data_ptr(), d_ns[k].data_ptr())
         if gather is not None:
-            gather(d_obs, d_rew, d_done[k])                              # obs / reward / done of every rank's shard
+            last_gathered[0] = gather(d_obs, d_rew, d_done[k])          # obs / reward / done of every rank's shard
         sim.reset_dev(None, d_rq[k].data_ptr(), d_rg[k].data_ptr())     # `if done: env.reset()`
 
     def barrier():
@@ -259,15 +263,20 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device="cpu" if args.rehearse_on_one_gpu else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    if args.dump_step and rank == 0:
+        if last_gathered[0] is not None:
+            np.save(args.dump_step, last_gathered[0].detach().cpu().numpy())
+        else:
+            np.save(args.dump_step, np.concatenate([d_obs.cpu().numpy(), d_rew.cpu().numpy()[:, None], d_done[W + K - 1].cpu().numpy()[:, None].astype(np.float32)], axis=1))
     substeps_done = int(d_ns[W:W + K].sum().item())
     dones = int(d_done[W:W + K].sum().item())
 
     # launch durations of the dominant kernel over the timed region (HIP events on the batch stream, one pair per launch)
     if persistent:
         # one launch = one env-step of every env (kinematics + collision + solve + integrate, 300 substeps in-kernel)
-        k_all = sim.kernel_times()
+        k_all = sim.kernel_times(cap=K)         # also the first synchronising call after the timed region: raises if a launch was drained by the work queue's watchdog
         sim.set_profiling(False)
-        k_all = k_all.reshape(K, -1).sum(axis=1)
+        assert len(k_all) == K, f"{len(k_all)} launches of the persistent kernel were timed, {K} env-steps ran"
         names = ["-", "-", "k_env_step_mf"]
         dom = 2
         units_per_launch = STEPS_PER_ACTION
@@ -294,10 +303,15 @@ def main():
     bytes_per_launch = bytes_per_substep_env * n * (mean_substeps if persistent else 1) + (4 * (m.nq + m.nv) + 5) * n * (1 if persistent else 0)
     achieved = bytes_per_launch / (avg_us * 1e-6) / 1e9
     traffic = None
+    traffic_source = None
     pmc = ROOT / "profiles" / "pmc_summary.json"
     if pmc.exists():
         try:
-            traffic = json.loads(pmc.read_text()).get(names[dom].split("<")[0], {}).get("hbm_bytes_per_launch")
+            pj = json.loads(pmc.read_text())
+            traffic = pj.get(names[dom].split("<")[0], {}).get("hbm_bytes_per_launch")
+            if traffic is not None:
+                traffic_source = ("profiles/pmc_summary.json (committed; rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --steps 1`, "
+                                  "not collected in this run): " + str(pj.get("_note", ""))[:160])
         except Exception:
             traffic = None
     value = world * n * K / dt
@@ -348,7 +362,8 @@ def main():
                    "substeps_per_s": value * mean_substeps, "persistent_kernel": persistent, "hipgraph": (not args.no_graph) and not persistent,
                    "bad_envs": int(bad.sum())},
         "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                     "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
+                     "binding": "valu",        # the prescribed roofline is HBM (BASELINE); what binds is FP32 VALU issue / latency: see `valu` and `note`
                      "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_us": avg_us, **kernel_stats,
                      "workgroup_lifetimes": lifetimes,
                      "valu": valu,
@@ -356,7 +371,8 @@ def main():
                      "launches_per_env_step": {nm: k for nm, k in zip(names, k_n) if nm != "-"},
                      "note": "state stays L2/MALL-resident; the path is FP32-VALU/latency bound, not HBM bound (SURVEY.md 8d)"},
     }
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and not args.no_cpu_baseline:
+        # rank 0 only, after the timed region (the other ranks wait at destroy_process_group): a line at N > 1 carries the baseline too
         out["cpu_baseline"] = cpu_baseline(m, q0, goal, ctrl_host, host_cores())
     elif rank == 0:
         out["cpu_baseline"] = None

@@ -238,12 +238,13 @@ __device__ __forceinline__ Geom load_geom_v(const DevModel &m, View xpos, View x
 // W > 1: the W consecutive lanes of a sub-group hold the SAME geom and direction and split the hull scan between them
 // (lane i takes vertices i, i + W, ...); a DPP butterfly picks the maximum, lowest index on ties - the same vertex the
 // sequential scan returns.
+enum { VID_BITS = 12, VID_NONE = (1 << VID_BITS) - 1 };      // a portal vertex id: three of them (+ 1) fit the three float rows of DevState::sepax as bit patterns
 template <int W> __device__ __forceinline__ void sup_merge(float &b, int &idx, float pb, int pi) {
     // bitwise, not short-circuit: `a || (b && c)` came back from the compiler as two nested exec-mask branches per merge step
     const bool take = (pb > b) | ((pb == b) & (pi < idx));
     b = take ? pb : b; idx = take ? pi : idx;
 }
-// vid (optional): which vertex it was - mesh: its index; box: the three sign bits; 0xff for the shapes without vertices.  A vertex id
+// vid (optional): which vertex it was - mesh: its index; box: the three sign bits; VID_NONE for the shapes without vertices (12 bits per shape: hulls of up to 4094 vertices; MAXMESHV bounds them far below).  A vertex id
 // names the same material point of the geom on the next substep (support_vertex), which is what the portal warm start needs.
 __device__ __forceinline__ v3 support_vertex(const Geom &G, int vid) {
     v3 loc;
@@ -254,7 +255,7 @@ __device__ __forceinline__ v3 support_vertex(const Geom &G, int vid) {
 template <int W = 1> __device__ __forceinline__ v3 support(const Geom &G, v3 dir, int *vid = nullptr) {
     const v3 dl = mulmtv(G.mat, dir);
     v3 loc;
-    if (vid) *vid = 0xff;
+    if (vid) *vid = VID_NONE;
     if (G.type == GEOM_BOX) {
         loc = mk3(dl.x > 0 ? G.size.x : -G.size.x, dl.y > 0 ? G.size.y : -G.size.y, dl.z > 0 ? G.size.z : -G.size.z);
         if (vid) *vid = (dl.x > 0 ? 1 : 0) | (dl.y > 0 ? 2 : 0) | (dl.z > 0 ? 4 : 0);
@@ -496,7 +497,8 @@ template <int CTRL> __device__ __forceinline__ float dppf_(float v) { return __b
 template <int Q> __device__ __forceinline__ int sg8_bcast(int v) { const int lo = dppi_<0x150 + Q>(v), hi = dppi_<0x158 + Q>(v); return (threadIdx.x & 8) ? hi : lo; }
 template <int Q> __device__ __forceinline__ float sg8_bcast(float v) { return __builtin_bit_cast(float, sg8_bcast<Q>(__builtin_bit_cast(int, v))); }
 __device__ __forceinline__ float sg8_next(float v) { return dppf_<0x101>(v); }
-__device__ __forceinline__ int collide_box_box_w8(const Geom &G1, const Geom &G2, float *con, int slot, int maxcnt, volatile float *scr) {
+struct NoStamp { __device__ __forceinline__ void operator()(int) const {} };
+template <class ST = NoStamp> __device__ __forceinline__ int collide_box_box_w8(const Geom &G1, const Geom &G2, float *con, int slot, int maxcnt, volatile float *scr, ST stamp = ST()) {
     const int sub = threadIdx.x & 7;
     v3 A[3], B[3];
     float s1[3] = {G1.size.x, G1.size.y, G1.size.z}, s2[3] = {G2.size.x, G2.size.y, G2.size.z};
@@ -527,6 +529,7 @@ __device__ __forceinline__ int collide_box_box_w8(const Geom &G1, const Geom &G2
         if (sep > best) { best = sep; code = 3 + j; bestn = B[j] * (t < 0 ? -1.f : 1.f); }
     }
     if (sepfound) return 0;
+    stamp(28);
     // edge axes q = 3 i + j: lane q evaluates axis q, lane 0 also axis 8
     float esep[2];
     int eok[2];
@@ -546,6 +549,11 @@ __device__ __forceinline__ int collide_box_box_w8(const Geom &G1, const Geom &G2
         esep[r] = fabsf(t) - (ra + rb);
         eL[r] = L * (t < 0 ? -1.f : 1.f);
     }
+    // The fold over the nine edge axes in their sequential order only ever RAISES `best`, so an axis that cannot beat the face axes' best
+    // cannot beat any later one either: when no lane of the sub-group holds
+    // an axis that separates or passes the first test (a face contact - the block resting on the table) the fold changes nothing and is skipped.
+    const bool cand = (eok[0] && (esep[0] > 0 || esep[0] * 1.05f > best + 1e-9f)) || ((threadIdx.x & 7) == 0 && eok[1] && (esep[1] > 0 || esep[1] * 1.05f > best + 1e-9f));
+    if ((((unsigned)(__ballot(cand) >> (threadIdx.x & 56))) & 0xffu) != 0u) {
     static_for<0, 9>([&](auto qc) {
         constexpr int q = decltype(qc)::value;
         const float sep = q < 8 ? sg8_bcast<q & 7>(esep[0]) : sg8_bcast<0>(esep[1]);
@@ -555,8 +563,10 @@ __device__ __forceinline__ int collide_box_box_w8(const Geom &G1, const Geom &G2
             if (sep * 1.05f > best + 1e-9f) { best = sep; code = 6 + q; }
         }
     });
+    }
     if (sepfound) return 0;
     if (code >= 6) bestn = code < 14 ? shfl3_8(eL[0], code - 6) : shfl3_8(eL[1], 0);
+    stamp(29);
     if (code < 6) {
         const bool ref1 = code < 3;
         const int ax = ref1 ? code : code - 3;
@@ -612,10 +622,22 @@ __device__ __forceinline__ int collide_box_box_w8(const Geom &G1, const Geom &G2
             P = mk3(scr[3 * sub], scr[3 * sub + 1], scr[3 * sub + 2]);
             __builtin_amdgcn_wave_barrier();
         };
+#ifndef HSR_NO_BB_FAST
+        // Resting contact (the block on the table): the whole incident face lies inside the four side planes of the reference face.  The four
+        // clips then copy the polygon unchanged - no vertex is outside (da <= 0 everywhere), so none is dropped and no edge is cut - and are
+        // skipped; `side` is the very expression the clip evaluates.
+        auto side = [&](v3 axis, float lim) { return dot(P - pr, axis) - lim; };
+        const bool in4 = sub >= 4 || (side(Au, su) <= 0 && side(-Au, su) <= 0 && side(Av, sv) <= 0 && side(-Av, sv) <= 0);
+        const bool all_in = (((unsigned)(__ballot(in4) >> (threadIdx.x & 56))) & 0xffu) == 0xffu;
+        if (!all_in)
+#endif
+        {
         clip(Au, su);
         if (np) clip(-Au, su);
         if (np) clip(Av, sv);
         if (np) clip(-Av, sv);
+        }
+        stamp(30);
         const float dist = dot(P - pr, nref) - sa;
         const bool hit = sub < np && dist < 0;
         const unsigned int hm = (unsigned int)((__ballot(hit) >> (threadIdx.x & 56)) & 0xffull);
@@ -652,7 +674,7 @@ __device__ __forceinline__ int collide_box_box_w8(const Geom &G1, const Geom &G2
 }
 
 // --- convex-convex: Minkowski Portal Refinement (libccd ccdMPRPenetration as used by mjc_Convex)
-struct Sup { v3 v, v1, v2; int id; };      // id: vertex ids of the two shapes (support()), id1 | id2 << 8
+struct Sup { v3 v, v1, v2; int id; };      // id: vertex ids of the two shapes (support()), id1 | id2 << VID_BITS
 #ifdef HSR_PHASE_TIMING
 __device__ int g_dbg_nsup_lane;   // unused placeholder to keep the symbol table stable
 #define DBG_COUNT_SUPPORT(ctr) (ctr)++
@@ -665,7 +687,7 @@ template <int W = 1> __device__ __forceinline__ Sup mpr_support(const Geom &G1, 
     int i1, i2;
     s.v1 = support<W>(G1, dir, &i1);
     s.v2 = support<W>(G2, -dir, &i2);
-    s.id = i1 | (i2 << 8);
+    s.id = i1 | (i2 << VID_BITS);
 #else
     s.v1 = support<W>(G1, dir);
     s.v2 = support<W>(G2, -dir);
@@ -745,7 +767,7 @@ template <int W = 1> __device__ bool mpr_penetration(const Geom &G1, const Geom 
     bool warm_ok = false;
 #ifndef HSR_MPR_COLD_ONLY
     if (warm && warm[0] > 0) {
-        auto rebuild = [&](int id, Sup &p) { p.id = id; p.v1 = support_vertex(G1, id & 0xff); p.v2 = support_vertex(G2, (id >> 8) & 0xff); p.v = p.v1 - p.v2; };
+        auto rebuild = [&](int id, Sup &p) { p.id = id; p.v1 = support_vertex(G1, id & VID_NONE); p.v2 = support_vertex(G2, (id >> VID_BITS) & VID_NONE); p.v = p.v1 - p.v2; };
         rebuild(warm[0] - 1, p1); rebuild(warm[1] - 1, p2); rebuild(warm[2] - 1, p3);
         // the ray from p0 through the origin crosses the triangle, with the winding the refinement expects (the three tests of the
         // portal discovery below), by a clear margin
@@ -829,7 +851,7 @@ template <int W = 1> __device__ bool mpr_penetration(const Geom &G1, const Geom 
             pos = (p0.v1 * b0 + p1.v1 * b1 + p2.v1 * b2 + p3.v1 * b3 + p0.v2 * b0 + p1.v2 * b1 + p2.v2 * b2 + p3.v2 * b3) * inv;
 #ifndef HSR_MPR_COLD_ONLY
             // the portal this run ended on, for the next substep - only vertices carry over (mesh, box)
-            auto vertex_ids = [](int id) { return (id & 0xff) != 0xff && ((id >> 8) & 0xff) != 0xff; };
+            auto vertex_ids = [](int id) { return (id & VID_NONE) != VID_NONE && ((id >> VID_BITS) & VID_NONE) != VID_NONE; };
             // (only from a run whose witness was interior: one that ended on a triangle edge would be started over next time anyway)
             if (warm && interior && vertex_ids(p1.id) && vertex_ids(p2.id) && vertex_ids(p3.id)) { warm[0] = p1.id + 1; warm[1] = p2.id + 1; warm[2] = p3.id + 1; }
 #endif

@@ -580,7 +580,9 @@ static int batch_init(hsr_batch *b, const hsr_model *m, int n_envs) {
             float *r = rec.data() + 16 * p;
             r[0] = (float)cd[p]; r[1] = (float)gl[g1[p]]; r[2] = (float)gl[g2[p]]; r[3] = (float)(iw[2 * g1[p]] + iw[2 * g2[p]]);
             for (int j = 0; j < 5; j++) r[4 + j] = (float)fr[5 * p + j];
-            r[9] = (float)sr[2 * p]; r[10] = (float)sr[2 * p + 1];
+            // [9], [10]: what the contact rows need of solref and solimp's dmax, formed here in double: B = 2 / (dmax timeconst), K = 1 / (dmax^2 timeconst^2 dampratio^2)
+            const double dmax = std::min(std::max(si[5 * p + 1], (double)HSR_MINIMP), (double)HSR_MAXIMP), tc = sr[2 * p], dr = sr[2 * p + 1];
+            r[9] = (float)(2.0 / (dmax * tc)); r[10] = (float)(1.0 / (dmax * dmax * tc * tc * dr * dr));
             for (int j = 0; j < 5; j++) r[11 + j] = (float)si[5 * p + j];
         }
         float *drec; if ((rc = dalloc(b, &drec, rec.size()))) return rc;
@@ -797,7 +799,8 @@ extern "C" int hsr_batch_kernel_times(hsr_batch *b, float *out_ms, int cap) {
         hipEventDestroy(pr.first); hipEventDestroy(pr.second);
     }
     b->klog.clear();
-    return n;
+    const int qe = queue_error(b);
+    return qe ? qe : n;
 }
 extern "C" int hsr_batch_set_graph(hsr_batch *b, int on) { NULLCHK(b); b->use_graph = on != 0; return HSR_OK; }
 __global__ void k_clear_margins(DevState s) {
@@ -819,7 +822,7 @@ extern "C" int hsr_batch_set_persistent(hsr_batch *b, int on) {
     return b->persist ? 1 : 0;
 }
 extern "C" int hsr_batch_is_persistent(const hsr_batch *b) { NULLCHK(b); return b->persist ? 1 : 0; }
-extern "C" int hsr_batch_set_debug(hsr_batch *b, int on) { if (!b) return fail(HSR_EINVAL, "null batch"); b->debug_store = (on & 1) != 0; b->test_hooks = on & (6 | 16); return HSR_OK; }
+extern "C" int hsr_batch_set_debug(hsr_batch *b, int on) { if (!b) return fail(HSR_EINVAL, "null batch"); b->debug_store = (on & 1) != 0; b->test_hooks = on & (6 | 16 | 32 | 64); return HSR_OK; }
 extern "C" int hsr_batch_set_schedule(hsr_batch *b, int on) { NULLCHK(b); b->schedule = on != 0; return HSR_OK; }
 extern "C" int hsr_batch_set_mpr_warm(hsr_batch *b, int on) {
     NULLCHK(b);
@@ -835,7 +838,8 @@ extern "C" int hsr_batch_set_queue(hsr_batch *b, int mode, int chunk) {
     if (chunk > 0) b->queue_chunk = chunk;
     return HSR_OK;
 }
-// the work queue's watchdog (persist.h: q_claim) tripped in some launch since the last check
+// the work queue's watchdog (persist.h: q_claim) tripped in some launch since the last check: the flag is sticky on the device (no launch
+// clears it) and only this function resets it, after reading it - every synchronising entry point ends with it
 static int queue_error(hsr_batch *b) {
     int err = 0;
     if (b->ds.q_err && hipMemcpy(&err, b->ds.q_err, sizeof err, hipMemcpyDeviceToHost) == hipSuccess && err) {
@@ -862,7 +866,7 @@ extern "C" int hsr_batch_cap_counts(hsr_batch *b, unsigned long long *out) {
     HIPCHK(hipStreamSynchronize(b->stream));
     HIPCHK(hipMemcpy(out, b->ds.capstat, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     HIPCHK(hipMemset(b->ds.capstat, 0, 4 * sizeof(unsigned long long)));
-    return HSR_OK;
+    return queue_error(b);
 }
 extern "C" int hsr_batch_cap_histogram(hsr_batch *b, unsigned long long *out) {
     if (!b || !out) return fail(HSR_EINVAL, "null argument");
@@ -970,7 +974,7 @@ extern "C" int hsr_batch_get_state(hsr_batch *b, float *time, float *qpos, float
     if (time && (rc = to_host_aos(b, time, b->ds.time, 1))) return rc;
     if (qpos && (rc = to_host_aos(b, qpos, b->ds.qpos, b->dm.nq))) return rc;
     if (qvel && (rc = to_host_aos(b, qvel, b->ds.qvel, b->dm.nv))) return rc;
-    return HSR_OK;
+    return queue_error(b);
 }
 extern "C" int hsr_batch_set_state(hsr_batch *b, const float *time, const float *qpos, const float *qvel) { NULLCHK(b);
     HIPCHK(hipSetDevice(b->device));
@@ -1002,7 +1006,7 @@ enum { SCHED_CHUNK = 8192 };
 __global__ void k_queue_init(DevState s, int T, int R) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < R) { s.q_head[i] = 0; s.q_wpos[i] = i == 0 ? T : 0; }
-    if (i == 0) *s.q_err = 0;
+    // q_err is NOT cleared here: a trip stays on record until the host has read it (queue_error), however many launches were enqueued since
     if (i < R * T) s.q_items[i] = i < T ? i : -1;
 }
 __global__ void __launch_bounds__(1024) k_schedule(DevState s, int epb, int *slot_env) {
@@ -1076,7 +1080,8 @@ extern "C" int hsr_batch_step_dev(hsr_batch *b, const float *d_ctrl, int n_subst
         }
         hipEvent_t k0 = nullptr, k1 = nullptr;
         if (b->kernel_log) { hipEventCreate(&k0); hipEventCreate(&k1); hipEventRecord(k0, st); }
-        hipLaunchKernelGGL(persist_kernel(b->dm, b->group, b->persist_tg), dim3(grid), dim3(64), b->persist_lds_bytes, st, (const DevModel *)b->d_dm, dsl, n_substeps, goal_body, geofence, (b->debug_store ? 1 : 0) | b->test_hooks | (b->mpr_warm ? 0 : 8), io);
+        hipLaunchKernelGGL(persist_kernel(b->dm, b->group, b->persist_tg), dim3(grid), dim3(64), b->persist_lds_bytes, st, (const DevModel *)b->d_dm, dsl, n_substeps, goal_body, geofence, (b->debug_store ? 1 : 0) | (b->test_hooks & ~32) | (b->mpr_warm ? 0 : 8), io);
+        if ((b->test_hooks & 32) && b->ds.q_err) HIPCHK(hipMemsetD32Async((hipDeviceptr_t)b->ds.q_err, 1, 1, st));      // tests: what q_claim's watchdog does when a ticket is never served
         if (b->kernel_log) { hipEventRecord(k1, st); b->klog.push_back({k0, k1}); }
         if (b->profiling) { hipEvent_t ev; hipEventCreate(&ev); hipEventRecord(ev, st); b->kev.push_back(ev); }   // slots 0,1 empty; slot 2 = the persistent kernel
     } else if (b->use_graph && !b->profiling && n_substeps > 0) {
@@ -1173,7 +1178,8 @@ extern "C" int hsr_batch_bad_state(hsr_batch *b, uint8_t *out) { NULLCHK(b);
     HIPCHK(hipStreamSynchronize(b->stream));
     int any = 0;
     for (int i = 0; i < b->N; i++) { out[i] = (uint8_t)(tmp[i] != 0); any |= tmp[i]; }
-    return any ? HSR_EBADSTATE : HSR_OK;
+    const int qe = queue_error(b);        // a drained launch outranks a diverged env: its envs stopped mid env-step
+    return qe ? qe : (any ? HSR_EBADSTATE : HSR_OK);
 }
 
 extern "C" int hsr_batch_get_field(hsr_batch *b, int field, float *out) { NULLCHK(b);

@@ -248,10 +248,14 @@ __device__ __forceinline__ Geom geom_cached3(const float *w, const float *cc, co
     return G;
 }
 // the oriented-box cull of pair_cull_box (collide.h) without data-dependent branches: both arms are evaluated and selected
-__device__ __forceinline__ bool pair_cull_box_nb(const Geom &G1, const Geom &G2, float rb1, float rb2) {
+// skin > 0: the test of "closer than skin" instead of "touching" (the item list of the persistent kernel is kept for several substeps,
+// persist.h): spheres and the first box grow by skin - a box grown by skin along its axes contains every point within skin of it
+__device__ __forceinline__ bool pair_cull_box_nb(const Geom &G1, const Geom &G2, float rb1, float rb2, float skin = 0.f) {
     const v3 n = col(G1.mat, 2);
-    const bool plane_pass = dot(G2.bc - G1.pos, n) - (fabsf(dot(n, col(G2.mat, 0))) * G2.bh.x + fabsf(dot(n, col(G2.mat, 1))) * G2.bh.y + fabsf(dot(n, col(G2.mat, 2))) * G2.bh.z) <= 0.f;
-    const bool s1 = sphere_hits_obb(G2.pos, rb2, G1), s2 = sphere_hits_obb(G1.pos, rb1, G2), ov = obb_overlap(G1, G2);
+    const bool plane_pass = dot(G2.bc - G1.pos, n) - (fabsf(dot(n, col(G2.mat, 0))) * G2.bh.x + fabsf(dot(n, col(G2.mat, 1))) * G2.bh.y + fabsf(dot(n, col(G2.mat, 2))) * G2.bh.z) <= skin;
+    Geom G1s = G1;
+    G1s.bh = mk3(G1.bh.x + skin, G1.bh.y + skin, G1.bh.z + skin);
+    const bool s1 = sphere_hits_obb(G2.pos, rb2 + skin, G1), s2 = sphere_hits_obb(G1.pos, rb1 + skin, G2), ov = obb_overlap(G1s, G2);
     return G1.type == GEOM_PLANE ? plane_pass : (s1 & s2 & ov);
 }
 // sphere-cull record of a candidate pair, one dword: geom1 (6 bits) | geom2 (6 bits) | narrowphase function (2 bits; 0 and 1 mean

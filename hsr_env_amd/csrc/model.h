@@ -27,7 +27,7 @@ struct DevModel {
     const int *pair_geom1, *pair_geom2, *pair_fn, *pair_condim, *pair_slot;
     const float *pair_friction, *pair_solref, *pair_solimp;
     const int *act_dof, *dof_act;     // dof_act[k]: actuator driving dof k or -1
-    const float *pair_rec;            // [npair][16]: dim l1 l2 tran fri[5] solref[2] solimp[5]
+    const float *pair_rec;            // [npair][16]: dim l1 l2 tran fri[5] B K solimp[5]  (B = 2 / (dmax timeconst), K = 1 / (dmax^2 timeconst^2 dampratio^2) of solref)
     const float *pair_geo;            // [npair][8]  g1 + 256 (geom1 is a plane)  g2  rbound1  rbound2 | fn slot maxcnt type1 (two float4 loads)
     const float *geom_rec;            // [ngeom][32] seven float4: link type nvert meshadr | lpos rbound | lmat[0..3] | lmat[4..7] | lmat[8] size | aabb centre - | aabb half -
     int npair_pad;                    // npair rounded up to 8: row length of the per-env pair-count table

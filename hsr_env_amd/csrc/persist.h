@@ -117,6 +117,7 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
     const int mode = 1, debug = 0;
     const bool dbg_store = flags & 1;          // introspection: contact counts / solver counters of each env's last substep go to global memory
     const bool hook_jv_per_contact = flags & 2, hook_majorant = flags & 4;      // tests: force the J v per contact / the PSD-majorant Newton step
+    const bool hook_no_item_list = flags & 64;        // tests: cull every substep (the behaviour before the item list was kept over substeps)
     const bool hook_ignore_stamps = flags & 16;      // tests: trust a separation margin whatever its stamp (the behaviour before the stamps existed)
     const bool mpr_warm = !(flags & 8);       // the portal of a penetrating convex pair is carried to its next substep (hsr_batch_set_mpr_warm)
     int cap_con = 0, cap_row = 0, cap_item = 0, nsub_run = 0;      // cap statistics of this lane's env (lane c == 0 reports)
@@ -192,7 +193,7 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
     // per-lane model constants of the solver: loaded once per launch (the registers are there since the exact-nv build)
     float my_ctrl = 0, damp_c = 0;
     int my_type = -1, my_qadr = 0, my_quat_lane = -1, my_limited = 0, my_act = -1;
-    float lim_lo = 0, lim_hi = 0, lim_sr0 = 1, lim_sr1 = 1, lim_iw = 0, lim_si[5] = {0, 0, 0, 0, 0};
+    float lim_lo = 0, lim_hi = 0, lim_sr0 = 1, lim_sr1 = 1, lim_iw = 0, lim_si[5] = {0, 0, 0, 0, 0}, lim_B = 0, lim_K = 0;
     float act_p[6] = {0, 0, 0, 0, 0, 0};
     {
         PERSIST_LANE_VIEW(tid0)
@@ -204,6 +205,7 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
             lim_iw = m.dof_invweight0[c];
 #pragma unroll
             for (int j = 0; j < 5; j++) lim_si[j] = m.dof_solimp[5 * c + j];
+        { const float dmax = fminf(fmaxf(lim_si[1], HSR_MINIMP), HSR_MAXIMP); lim_B = 2.0f / (dmax * lim_sr0); lim_K = 1.0f / (dmax * dmax * lim_sr0 * lim_sr0 * lim_sr1 * lim_sr1); }
             if (my_act >= 0) {
                 act_p[0] = m.act_kp[my_act]; act_p[1] = m.act_gear[my_act];
                 act_p[2] = m.act_ctrlrange[2 * my_act]; act_p[3] = m.act_ctrlrange[2 * my_act + 1];
@@ -223,6 +225,14 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
     const bool first_run = sub0 == 0, last_run = sub1 >= n_substeps;
     const bool fresh = io.ctrl != nullptr && first_run;       // HSREnv.step begins here: ctrl[:] = action, a fresh done flag (hsr/env.py:116,124)
     cap_con = cap_row = cap_item = nsub_run = own_trips = 0; bad_acc = trips_acc = 0; nsteps_e = 0;
+    // Item list of the narrowphase, kept over several substeps (HSR_SKIN > 0): it is built from culls that ask "closer than HSR_SKIN"
+    // instead of "touching", and holds until some geom of some env of the workgroup may have moved half of that since (upper bounds of
+    // the moves, the ones the separation margins of the convex pairs use).  A pair that is not on the list was farther apart than the
+    // skin when the list was built and has closed in by less since: no contact.  A pair on it runs its narrowphase every substep -
+    // which reports a contact only where there is one - so the contact set is the one of culling every substep.
+    int nitems = 0;                                        // wave-uniform
+    bool list_ok = false;                                  // wave-uniform: sItems[0 .. nitems) is a valid list
+    float acc_move = 0.f;                                  // this lane's env: bound on the move of any of its geoms since the list was built
     // ---------------- load the env state; it lives in registers for the whole run of substeps
     {
         PERSIST_LANE_VIEW(tid0)
@@ -319,6 +329,7 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
             auto gaddr = [&](int gi, const float *Ei) -> const float * { return gi < nstat ? lds + L.oGeomS + 16 * gi : Ei + oGw + 16 * (gi - nstat); };
             const float *gcc;
             if constexpr (TG) gcc = s.geom_c; else gcc = lds + L.oGeomC;
+            float mymove = 0.f;
             if (valid) {
                 for (int gm = c; gm < nmov; gm += G) {
                     const GeomPlaceC k2 = gm < G ? gpc : geom_place_consts(m.geom_rec + 32 * (nstat + gm));
@@ -329,9 +340,14 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
                     const float4 lv0 = kl4(recL + 12 * k2.link);
                     const v3 lw = mk3(lv0.x, lv0.y, lv0.z), lvo = mk3(lv0.w, recL[12 * k2.link + 4], recL[12 * k2.link + 5]);
                     const v3 vg = lvo + cross(lw, mulmv(Rl, mk3(k2.q1.x, k2.q1.y, k2.q1.z)));
-                    geom_place3(k2, Rl, pl, gw + 16 * gm, 1.25f * m.timestep * (norm(vg) + norm(lw) * k2.q1.w) + 1e-7f);
+                    const float smove = 1.25f * m.timestep * (norm(vg) + norm(lw) * k2.q1.w) + 1e-7f;
+                    geom_place3(k2, Rl, pl, gw + 16 * gm, smove);
+                    mymove = fmaxf(mymove, smove);
                 }
             }
+            acc_move += __int_as_float(gmax<G>(__float_as_int(mymove)));      // non-negative floats order like their bit patterns
+            const float skin = hook_no_item_list ? 0.f : HSR_SKIN;
+            const bool rebuild = skin <= 0.f || !list_ok || wave_any(valid && 2.f * acc_move >= skin);
             for (int p0 = 0; p0 < m.npair_pad / 4; p0 += G) { const int p = p0 + c; if (p < m.npair_pad / 4) reinterpret_cast<int *>(pcnt)[p] = 0; }
             wave_sync();
             PHASE_K(30);
@@ -339,7 +355,9 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
             const unsigned *sPair;
             if constexpr (TG) sPair = s.pair_pack; else sPair = reinterpret_cast<const unsigned *>(lds + L.oPair);
             unsigned short *sCand = reinterpret_cast<unsigned short *>(poly);      // 128 entries in the box-box polygon scratch (dead during the culls)
-            int ncand = 0, nitems = 0;                             // wave-uniform
+            if (rebuild) {
+            int ncand = 0;                                         // wave-uniform
+            nitems = 0;
             int nit_env[EPB];                                      // items per env (wave-uniform): an env keeps at most 64, whatever its neighbours do
 #pragma unroll
             for (int j = 0; j < EPB; j++) nit_env[j] = 0;
@@ -355,8 +373,9 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
                     const int g1 = pk_g1(pk), g2 = pk_g2(pk);
                     float rb1, rb2;
                     const Geom A = geom_cached3(gaddr(g1, Ei), gcc + 8 * g1, m.mesh_vert4, rb1), B = geom_cached3(gaddr(g2, Ei), gcc + 8 * g2, m.mesh_vert4, rb2);
-                    pass = pair_cull_box_nb(A, B, rb1, rb2);
+                    pass = pair_cull_box_nb(A, B, rb1, rb2, skin);
                 }
+                PHASE_S(2, 28);
                 const unsigned long long lower = (1ull << tid) - 1ull;
                 const int ig = it >> 14;
                 bool accept = false;
@@ -376,6 +395,7 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
                 if (tid < rest) sCand[tid] = mv;
                 wave_sync();
                 ncand = rest;
+                PHASE_S(2, 29);
             };
             // level 1: lane c of every env tests eight consecutive pairs per pass (their packed records are two LDS reads, the
             // positions / plane normals 24 more, all issued before the first test); the survivors of all envs are appended to the
@@ -397,13 +417,14 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
                         mybits = 0;
 #pragma unroll
                         for (int q = 0; q < 8; q++) {
-                            const float rad = __uint_as_float(pk[q] & 0xffff0000u);
+                            const float rad = __uint_as_float(pk[q] & 0xffff0000u) + skin;
                             const v3 r = mk3(a2[q].x - a1[q].x, a2[q].y - a1[q].y, a2[q].z - a1[q].z);
                             const float dpl = dot(r, mk3(nn[q].x, nn[q].y, nn[q].z)), dsq = dot(r, r);
                             const bool hit = pk_fn(pk[q]) <= FN_PLANE_CONVEX ? dpl <= rad : dsq <= rad * rad;
                             mybits |= (valid && p0 + q < m.npair && hit) ? 1u << q : 0u;
                         }
                         u = 0; pb += 8 * G;
+                        PHASE_S(2, 26);
                     }
                     while (u < 8 && ncand < 64) {
                         const bool pass = (mybits >> u) & 1u;
@@ -412,15 +433,18 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
                         ncand += __popcll(bal);
                         u++;
                     }
+                    PHASE_S(2, 27);
                     const bool more = u < 8 || pb < m.npair;
                     if (ncand >= 64 || (!more && ncand > 0)) { wave_sync(); box_round(); }
                     else if (!more) break;
                 }
             }
             wave_sync();
-            PHASE(19);
 #pragma unroll
             for (int j = 0; j < EPB; j++) if (g == j && nit_env[j] > 64) cap_item += valid ? 1 : 0;      // more than 64 surviving pairs in ONE env: its contacts beyond them are dropped (a capacity event, counted in capstat[2]; NOT a diverged state)
+            acc_move = 0.f; list_ok = true;
+            }
+            PHASE(19);
             DBGCNT(2, nitems);
             wave_sync();
             for (int ib = 0; ib < nitems; ib += 64) {
@@ -448,54 +472,72 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
                     *cntp = (unsigned char)out.cnt;
                 }
                 PHASE(21);
-                // convex pairs (MPR): one work item per MW-lane sub-group, the lanes share the hull scans of the support function
+                // convex pairs (mesh / cylinder against box / mesh)
+                // Pass 1, lane = item: temporal coherence.  The pair keeps the direction d that separated it last time and how much of that
+                // separation is left after the geoms' moves since (upper bounds, geom cache slot 15): while it is positive the pair is
+                // still separated along d and that is all there is to do - one lane, no geoms, every such item of the wave at once.
+                // The margin is only worth anything if it was brought up to date on the env's PREVIOUS substep: a pair that was off the
+                // item list in between has moved by amounts nobody subtracted - its stamp (the env's substep count at the last visit)
+                // then differs from tick - 1 and the margin counts as 0.
+                // Pass 2, one MW-lane sub-group per item that needs its hulls (the lanes share the scans of the support function): both
+                // hulls are scanned along d and the margin is refreshed; MPR runs only when d no longer separates - from the portal of the
+                // previous substep if the pair penetrated then (margin row = -1: rows 0-2 hold its vertex ids).
                 {
                     constexpr int MW = 8;
                     const bool cv = fn == FN_CONVEX;
-                    const unsigned long long cbal = __ballot(cv);
-                    if (cv) sMpr[__popcll(cbal & ((1ull << tid) - 1ull))] = (unsigned char)tid;
+                    float cdx = 0.f, cdy = 0.f, cdz = 0.f, cmg = 0.f;
+                    int cfresh = 0;
+                    bool need = false;
+                    if (cv) {
+                        const int p1 = it & 0x3fff, ig1 = it >> 14;
+                        float *sx1 = s.sepax + (size_t)(4 * p1) * N + sEnv[ig1];
+                        int *stamp1 = s.septick + (size_t)p1 * N + sEnv[ig1];
+                        cdx = sx1[0]; cdy = sx1[N]; cdz = sx1[2 * (size_t)N]; cmg = sx1[3 * (size_t)N];
+                        const int tick1 = sTick[ig1];
+                        cfresh = (*stamp1 == tick1 - 1 || hook_ignore_stamps) ? 1 : 0;
+                        need = true;
+                        if (cmg >= 0.f && (cdx != 0.f || cdy != 0.f || cdz != 0.f)) {
+                            const unsigned pk1 = sPair[p1];
+                            const float *Ei1 = lds + (size_t)ig1 * L.envf;
+                            const float left = (cfresh ? cmg : 0.f) - (gaddr(pk_g1(pk1), Ei1)[15] + gaddr(pk_g2(pk1), Ei1)[15]);
+                            if (left > 0.f) { sx1[3 * (size_t)N] = left; *stamp1 = tick1; need = false; }      // still separated along d (its contact count stays 0)
+                        }
+#ifdef HSR_PAIR_HIST
+                        atomicAdd(&s.phase_cyc[32 + 40 * 4096 + p1], 1ull);       // tools/exp_pairs.py: convex items per pair
+#endif
+                    }
+                    const unsigned long long cbal = __ballot(need);
+                    if (need) sMpr[__popcll(cbal & ((1ull << tid) - 1ull))] = (unsigned char)tid;
                     const int ncv = __popcll(cbal);
                     wave_sync();
+                    PHASE_M(26);
                     for (int r0 = 0; r0 < ncv; r0 += 64 / MW) {
                         const int k = r0 + tid / MW;
+                        // what pass 1 read for the item, out of the registers of the lane that read it
+                        const int srcl = 4 * (int)sMpr[k < ncv ? k : 0];
+                        v3 d = mk3(__int_as_float(__builtin_amdgcn_ds_bpermute(srcl, __float_as_int(cdx))), __int_as_float(__builtin_amdgcn_ds_bpermute(srcl, __float_as_int(cdy))),
+                                   __int_as_float(__builtin_amdgcn_ds_bpermute(srcl, __float_as_int(cdz))));
+                        const float mg0 = __int_as_float(__builtin_amdgcn_ds_bpermute(srcl, __float_as_int(cmg)));
+                        const bool fresh_cache = __builtin_amdgcn_ds_bpermute(srcl, cfresh) != 0;
                         if (k < ncv) {
                             const int it2 = sItems[ib + sMpr[k]];
                             Geom H1, H2; ContactOut o2; unsigned char *cntp;
                             item_geoms(it2, H1, H2, o2, cntp);
-                            // temporal coherence: the direction d that separated the pair last time, and how much of that
-                            // separation is left after the geoms' moves since (upper bounds, geom cache slot 15): while it is
-                            // positive the pair is still separated along d and nothing is scanned; otherwise both hulls are scanned
-                            // along d and the margin is refreshed; MPR runs only when d no longer separates.
-                            // The margin is only worth anything if it was brought up to date on the env's PREVIOUS substep: a pair that
-                            // was culled (spheres, boxes, item cap) in between has moved by amounts nobody subtracted - its stamp
-                            // (the env's substep count at the last visit) then differs from tick - 1 and the margin counts as 0.
-                            PHASE_M(26);
                             float *sx = s.sepax + (size_t)(4 * (it2 & 0x3fff)) * N + sEnv[it2 >> 14];
-                            v3 d = mk3(sx[0], sx[N], sx[2 * (size_t)N]);
-                            float mg = sx[3 * (size_t)N];
                             int *stampp = s.septick + (size_t)(it2 & 0x3fff) * N + sEnv[it2 >> 14];
                             const int tick_now = sTick[it2 >> 14];
-                            const bool fresh_cache = *stampp == tick_now - 1 || hook_ignore_stamps;
+                            float mg = 0.f;
                             int wid[3] = {0, 0, 0};
                             // a pair that penetrated on the previous substep left the vertex ids of its final portal instead of a
-                            // separating direction (margin row = -1): the portal warm start of mpr_penetration
-                            if (mg < 0.f) {
+                            // separating direction: the portal warm start of mpr_penetration
+                            if (mg0 < 0.f) {
                                 if (fresh_cache && mpr_warm) { wid[0] = __float_as_int(d.x); wid[1] = __float_as_int(d.y); wid[2] = __float_as_int(d.z); }
-                                d = mk3(0, 0, 0); mg = 0.f;
+                                d = mk3(0, 0, 0);
                             }
-                            if (!fresh_cache) mg = 0.f;
-                            {
-                                const unsigned pk2 = sPair[it2 & 0x3fff];
-                                const float *Ei2 = lds + (size_t)(it2 >> 14) * L.envf;
-                                mg -= gaddr(pk_g1(pk2), Ei2)[15] + gaddr(pk_g2(pk2), Ei2)[15];
-                            }
-#ifdef HSR_PAIR_HIST
-                            if ((tid & (MW - 1)) == 0) atomicAdd(&s.phase_cyc[32 + 40 * 4096 + (it2 & 0x3fff)], 1ull);       // tools/exp_pairs.py: convex items per pair
-#endif
                             const bool have = d.x != 0.f || d.y != 0.f || d.z != 0.f;
-                            bool still = have && mg > 0.f;
+                            bool still = false;                   // pass 1 found no margin left
                             PHASE_M(27);
-                            if (have && !still) {
+                            if (have) {
                                 const float gap = -dot(support<MW>(H1, d) - support<MW>(H2, -d), d);
                                 still = gap > 1e-7f;
                                 mg = still ? 0.98f * gap : 0.f;
@@ -535,12 +577,14 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
                     if (bb) sMpr[__popcll(bbal & ((1ull << tid) - 1ull))] = (unsigned char)tid;
                     const int nbb = __popcll(bbal);
                     wave_sync();
+                    PHASE_S(3, 26);
                     for (int r0 = 0; r0 < nbb; r0 += 8) {
                         const int k = r0 + tid / 8;
                         if (k < nbb) {
                             Geom G1, G2; ContactOut out; unsigned char *cntp;
                             item_geoms(sItems[ib + sMpr[k]], G1, G2, out, cntp);
-                            const int cnt = collide_box_box_w8(G1, G2, out.con, out.slot, out.maxcnt, poly + 24 * (tid / 8));
+                            PHASE_S(3, 27);
+                            const int cnt = collide_box_box_w8(G1, G2, out.con, out.slot, out.maxcnt, poly + 24 * (tid / 8), [&](int idx) { (void)idx; if (idx == 28) { PHASE_S(3, 28); } else if (idx == 29) { PHASE_S(3, 29); } else if (idx == 30) { PHASE_S(3, 30); } else { PHASE_S(3, 31); } });
                             if ((tid & 7) == 0) *cntp = (unsigned char)cnt;
                         }
                     }
@@ -609,6 +653,7 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
                 if (bad) bad_acc = 1;
                 if (reach) done = true;          // a-4: latch; the env skips the remaining substeps
             }
+            if (wave_any(valid && reach)) list_ok = false;      // the items of an env that just finished leave the list
             trips_acc += newton_trips;
             if (valid && n_substeps - sub <= 100) own_trips += iter;
             wave_sync();

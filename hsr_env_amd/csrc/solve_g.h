@@ -20,6 +20,9 @@
 #ifndef HSR_LS_REL
 #define HSR_LS_REL 1e-2f        // relative stop of the exact line search: |phi'(alpha)| < HSR_LS_REL |phi'(0)|  (1e-3: same iteration counts, launch 2.6 % longer)
 #endif
+#ifndef HSR_SKIN
+#define HSR_SKIN 0.01f          // persist.h: the narrowphase item list is built for "closer than this" and kept until a geom may have moved half of it (0: culls every substep)
+#endif
 #ifdef HSR_PHASE_TIMING
 // diagnostic build only: stamp = one asm statement (s_memtime + its wait) fenced by sched_barriers, sums kept in
 // registers and flushed once at the end (cdna_hip_programming.md section 7, in-kernel stamps)
@@ -49,14 +52,18 @@ __device__ __forceinline__ unsigned long long stamp_() {
 #define PHASE(idx) do {} while (0)
 #define PHASE_FLUSH() do {} while (0)
 #endif
-// the six spare stamps: the kinematics stages by default, the inside of the MPR section with -DHSR_MPR_PROFILE (timing build)
+// the six spare stamps (26..31): the kinematics stages by default; a timing build with -DHSR_SUBPROF=n moves them inside ONE other phase
+// (1 the MPR section - the old -DHSR_MPR_PROFILE -, 2 the sphere / box culls, 3 box-box, 4 inertia + bias, 5 constraint assembly,
+// 6 the warm-start choice, 7 one Newton iteration's Hessian); tools/block_times.py names them by HSR_SUBPROF
 #ifdef HSR_MPR_PROFILE
-#define PHASE_K(idx) do {} while (0)
-#define PHASE_M(idx) PHASE(idx)
-#else
-#define PHASE_K(idx) PHASE(idx)
-#define PHASE_M(idx) do {} while (0)
+#define HSR_SUBPROF 1
 #endif
+#ifndef HSR_SUBPROF
+#define HSR_SUBPROF 0
+#endif
+#define PHASE_S(n, idx) do { if constexpr (HSR_SUBPROF == (n)) { PHASE(idx); } } while (0)
+#define PHASE_K(idx) PHASE_S(0, idx)
+#define PHASE_M(idx) PHASE_S(1, idx)
 // DPP controls (gfx90a+): row_shr:n = 0x110+n, row_ror:n = 0x120+n, row_newbcast:n = 0x150+n; a "row" is 16 lanes,
 // exactly one 16-lane env group, so these are single full-rate VALU modifiers instead of ds_bpermute round trips
 template <int CTRL, bool ZERO_OOB> __device__ __forceinline__ float dpp_f(float v) {

@@ -147,7 +147,7 @@ __global__ void __launch_bounds__(64, 2) k_solve_mf(DevModel m, DevState s, int 
     const int *pair_cnt_ = s.ncon_pair + (size_t)e * m.npair_pad;
     float qvel_c = 0, warm_c = 0, my_q = 0, my_ctrl = 0, damp_c = 0;
     int my_type = -1, my_qadr = 0, my_quat_lane = -1, my_limited = 0, my_act = -1;
-    float lim_lo = 0, lim_hi = 0, lim_sr0 = 1, lim_sr1 = 1, lim_iw = 0, lim_si[5] = {0, 0, 0, 0, 0};
+    float lim_lo = 0, lim_hi = 0, lim_sr0 = 1, lim_sr1 = 1, lim_iw = 0, lim_si[5] = {0, 0, 0, 0, 0}, lim_B = 0, lim_K = 0;
     float act_p[6] = {0, 0, 0, 0, 0, 0};
     if (isdof) {
         my_type = m.dof_type[c]; my_qadr = m.dof_qposadr[c]; my_limited = m.dof_limited[c]; my_act = m.dof_act[c];
@@ -158,6 +158,7 @@ __global__ void __launch_bounds__(64, 2) k_solve_mf(DevModel m, DevState s, int 
         lim_iw = m.dof_invweight0[c];
 #pragma unroll
         for (int j = 0; j < 5; j++) lim_si[j] = m.dof_solimp[5 * c + j];
+        { const float dmax = fminf(fmaxf(lim_si[1], HSR_MINIMP), HSR_MAXIMP); lim_B = 2.0f / (dmax * lim_sr0); lim_K = 1.0f / (dmax * dmax * lim_sr0 * lim_sr0 * lim_sr1 * lim_sr1); }
         my_q = s.qpos[(size_t)my_qadr * N + e];
         if (my_act >= 0) {
             my_ctrl = s.ctrl[(size_t)my_act * N + e];

@@ -237,6 +237,8 @@ class BatchSim:
     def bad_state(self):
         out = np.empty(self.n, np.uint8)
         rc = self._L.hsr_batch_bad_state(self._b, out.ctypes.data_as(C.POINTER(C.c_uint8)))
+        if rc not in (0, -5):
+            _check(self._L, rc)
         return out.astype(bool), rc == -5
 
     def get_field(self, field: int):
@@ -267,7 +269,9 @@ class BatchSim:
         n = self._L.hsr_batch_kernel_times(self._b, buf, cap)
         if n < 0:
             _check(self._L, n)
-        return np.array(buf[:min(n, cap)], dtype=np.float64)
+        if n > cap:
+            raise ValueError(f"{n} launches were logged, the buffer holds {cap}: pass cap >= the number of launches since the last call")
+        return np.array(buf[:n], dtype=np.float64)
 
     def set_graph(self, on: bool):
         _check(self._L, self._L.hsr_batch_set_graph(self._b, int(on)))

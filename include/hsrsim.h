@@ -128,7 +128,10 @@ int hsr_batch_is_persistent(const hsr_batch *b);
  * `on` is a bit mask: 1 = the above; 2 and 4 are test hooks that force rarely taken branches of the Newton solver of the persistent
  * kernel (2: J v per contact instead of per link; 4: every iteration takes the PSD-majorant Hessian) - same minimiser, other path;
  * 16 makes the convex-pair section trust a cached separation margin whatever its stamp - the round-2 behaviour, kept so that the test of
- * the stamps can show what they prevent. */
+ * the stamps can show what they prevent; 64 makes the persistent kernel cull every substep instead of keeping its narrowphase item list
+ * until a geom may have moved half a skin (the behaviour up to round 3; the contact sets are the same either way); 32 raises the work queue's watchdog flag after every persistent launch (what a ticket that is
+ * never served does): the flag is sticky on the device, the next synchronising call (hsr_batch_sync, _step, _kernel_times, _cap_counts,
+ * _bad_state, _get_state) returns HSR_EDEVICE once and clears it. */
 int hsr_batch_set_debug(hsr_batch *b, int on);
 /* wave packing of the persistent kernel (default on; HSR_SCHEDULE=0 turns it off at creation): before every launch the envs are re-distributed over the waves by the
  * Newton iterations they needed at the end of their previous launch (hard envs one per wave, with the easiest as neighbours).

@@ -57,10 +57,17 @@ def oracle_rollout(m, q, v, ctrl, nsteps):
     return sims
 
 
+# envs of the forward-stage test whose contact COUNT differs from the oracle's (a contact at the edge of existence in one precision):
+# their kinematics, inertia and smooth acceleration are compared like everyone's, only the contact records and the constrained
+# acceleration are not - and how many there may be is pinned per configuration to what was measured (round 4), not a blanket share
+FORWARD_NCON_MISMATCH = {"cfg1": 0, "cfg2": 0, "cfg3": 0, "cfg4": 0, "cupboard": 0}
+
+
 @pytest.mark.parametrize("cfg", ["cfg1", "cfg2", "cfg3", "cfg4", "cupboard"])
 def test_forward_stages_match_oracle(models, cfg):
-    """sim.forward(): kinematics (|dx| < 2e-6), inertia (rel 1e-5), smooth acceleration (rel 2e-4),
-    contact set (same count; pos/normal/dist 1e-4), constrained acceleration (abs 2e-2 + rel 2e-3)."""
+    """sim.forward(): kinematics (|dx| < 2e-6), inertia (rel 1e-5), smooth acceleration (rel 2e-4) for EVERY env;
+    contact set (same count; pos/normal/dist 1e-4) and constrained acceleration (abs 2e-2 + rel 2e-3) for every env whose contact
+    count equals the oracle's - the others are counted and the count is pinned (FORWARD_NCON_MISMATCH)."""
     m = models[cfg]
     n = 96
     rng = np.random.default_rng(10)
@@ -95,7 +102,8 @@ def test_forward_stages_match_oracle(models, cfg):
         assert np.allclose(gc[:, 3:6], oc[:, 3:6], atol=2e-3)
         assert np.allclose(gc[:, 0:3], oc[:, 0:3], atol=2e-4)
         assert np.allclose(qacc[e], o.qacc, rtol=2e-3, atol=2e-2), (e, qacc[e], o.qacc)
-    assert nmis <= max(1, n // 50), f"{nmis} envs with a different contact count"
+    print(f"{cfg}: {nmis} of {n} envs with a contact count different from the oracle's (pinned: {FORWARD_NCON_MISMATCH[cfg]})")
+    assert nmis <= FORWARD_NCON_MISMATCH[cfg], f"{nmis} envs with a different contact count"
     sim.close()
 
 
@@ -152,12 +160,77 @@ def test_single_substep_matches_oracle(models, cfg):
     sim.close()
 
 
+def contact_mismatch(m, slots, oc):
+    """None when the HIP contact records slots[nslot,7] (pos3 normal3 dist; dist = +1: empty) equal the oracle's oc[k,17] to fp32
+    tolerance, else a reason.  Contacts are matched pair by pair; inside a pair (box-box: up to 8 points) the order of the points
+    is free - the 8-lane clipper emits the polygon from another starting vertex than the sequential one."""
+    used = slots[:, 6] <= 0
+    if int(used.sum()) != len(oc):
+        return f"count {int(used.sum())} vs {len(oc)}"
+    for p in range(m.npair):
+        a, b = int(m.pair_slot[p]), int(m.pair_slot[p + 1])
+        gp = slots[a:b][used[a:b]]
+        op = oc[(oc[:, 13] == m.pair_geom1[p]) & (oc[:, 14] == m.pair_geom2[p])]
+        if len(gp) != len(op):
+            return f"count of pair {p}: {len(gp)} vs {len(op)}"
+        left = list(range(len(op)))
+        for g in gp:
+            k = min(left, key=lambda i: np.abs(op[i, 0:3] - g[0:3]).max())
+            left.remove(k)
+            if abs(g[6] - op[k, 12]) > 1e-5:
+                return f"depth {abs(g[6] - op[k, 12]):.2e} (pair {p})"
+            if np.abs(g[3:6] - op[k, 3:6]).max() > 2e-3:
+                return f"normal {np.abs(g[3:6] - op[k, 3:6]).max():.2e} (pair {p})"
+            if np.abs(g[0:3] - op[k, 0:3]).max() > 2e-4:
+                return f"position {np.abs(g[0:3] - op[k, 0:3]).max():.2e} (pair {p})"
+    return None
+
+
+def first_contact_divergence(m, q0, ctrl, nsub):
+    """Replays env-steps substep by substep on the GPU (one launch per substep, contact records stored) and in the oracle; returns per env
+    the first substep at which the two contact LISTS differ beyond the stage tolerances (contact_mismatch: the number of contacts of some
+    candidate geom pair, or a depth / normal / position: -1 = never), the largest |dobs| seen before that substep, and what differed."""
+    n = q0.shape[0]
+    sim = hs.BatchSim(m, n)
+    sim.set_debug(True)
+    sim.set_state(np.zeros(n), q0, np.zeros((n, m.nv)))
+    orc = []
+    for e in range(n):
+        o = OracleSim(m)
+        o.qpos[:] = q0[e]; o.ctrl[:] = ctrl[e]
+        orc.append(o)
+    first = np.full(n, -1); before = np.zeros(n); reason = [None] * n; big = [None] * n
+    for k in range(nsub):
+        obs = sim.step(ctrl, 1)[0]
+        con = sim.get_field(hs.F_CONTACT)
+        for e, o in enumerate(orc):
+            if first[e] >= 0:
+                continue
+            o.step()
+            why = contact_mismatch(m, con[e], o.contacts())
+            if why is not None:
+                reason[e] = why
+                first[e] = k
+            else:
+                dd = np.abs(obs[e] - np.concatenate([o.qpos, o.qvel]))
+                before[e] = max(before[e], float(dd.max()))
+                if big[e] is None and dd.max() >= 2e-3:
+                    big[e] = (k, int(dd.argmax()), float(dd.max()), int(sim.get_field(hs.F_NITER)[e]), int(o.solver_niter))
+        if (first >= 0).all():
+            break
+    sim.close()
+    return first, before, reason, big
+
+
 @pytest.mark.parametrize("cfg", ["cfg1", "cfg2", "cfg3", "cfg4", "cupboard"])
 def test_env_step_300_matches_oracle(models, cfg):
-    """A whole env-step (300 substeps): median |dobs| < 1e-4, 90th percentile < 2e-3 (contact
-    dynamics amplify fp32 rounding over 300 steps; per-substep parity is the sharp test).  In the cupboard scene
-    a random ctrl drives the arm into the doors in a fifth of the envs, which is chaotic in either precision:
-    there the bound is on the 75th percentile."""
+    """A whole env-step (300 substeps): median |dobs| < 1e-4, 90th percentile < 2e-3 (contact dynamics amplify fp32 rounding over
+    300 steps; per-substep parity is the sharp test; in the cupboard scene a random ctrl drives the arm into the doors in a fifth of
+    the envs, which is chaotic in either precision: there the percentile bound is on the 75th).  And no env beyond 2e-3 goes
+    unexplained: both sides are replayed substep by substep and the env must show a substep at which the HIP contact LIST differs from
+    the oracle's beyond the stage tolerances - a contact that exists in one precision only, or (flat finger face on a flat door: the
+    single MPR point of a face-face pair is not unique) one whose position / normal / depth the two precisions place differently; from there
+    on the two runs are different trajectories - with the two still within 2e-3 of each other up to that substep."""
     m = models[cfg]
     n = 64
     rng = np.random.default_rng(12)
@@ -176,6 +249,15 @@ def test_env_step_300_matches_oracle(models, cfg):
     assert np.percentile(errs, 75 if cfg == "cupboard" else 90) < 2e-3, errs
     assert (ns == 300).all()
     sim.close()
+    out = np.flatnonzero(errs >= 2e-3)
+    if len(out):
+        first, before, reason, big = first_contact_divergence(m, q[out], ctrl[out], 300)
+        print(f"{cfg}: {len(out)} of {n} envs beyond 2e-3 after 300 substeps; first substep with a differing contact list {first.tolist()}, "
+              f"largest |dobs| before it {np.array2string(before, precision=1)}, what differed: {reason}; first (substep, obs index, |dobs|, HIP Newton iterations, oracle's) beyond 2e-3 while the lists still agreed: {big}")
+        assert (first >= 0).all(), f"envs {out[first < 0].tolist()} are beyond 2e-3 without any divergence of the contact sets"
+        assert (before < 2e-3).all(), (out.tolist(), before)
+    else:
+        print(f"{cfg}: no env beyond 2e-3 after 300 substeps")
 
 
 def test_goal_early_exit_matches_oracle(models):

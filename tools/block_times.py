@@ -50,7 +50,20 @@ coef = np.linalg.lstsq(A, life * 300 / 300, rcond=None)[0]
 print('life us ~ %.0f + %.2f * newton_trips + %.2f * items + %.2f * nefc' % tuple(coef))
 
 names = ['A load', 'B/C M+bias', 'D chol M', 'E1-2', 'E3', 'E4-5', 'F0 warm', 'F grad', 'F hess', 'F chol', 'F ls loop', 'F eval', 'G(12)', 'F ls mv+sums(13)', 'exit+qfc(14)', 'G chol(15)',
-         'K kin(16)', 'C(17)', 'integrate(18)', 'C cull1(19)', 'C cull2(20)', 'C plane(21)', 'C mpr(22)', 'C boxbox(23)', 'K pose(24)', 'F ls jmul(25)', 'x26', 'x27', 'x28', 'x29', 'x30', 'x31']
+         'K kin(16)', 'C(17)', 'integrate(18)', 'C cull1(19)', 'C cull2(20)', 'C plane(21)', 'C mpr(22)', 'C boxbox(23)', 'K pose(24)', 'F ls jmul(25)']
+# the six spare stamps 26..31 (solve_g.h: HSR_SUBPROF of the timing build; say which with the environment variable of the same name)
+SUB = {0: ['K A local transforms', 'K B world poses', 'K C dof axes', 'K D velocity fields', 'C geom placement', 'K goal test + xpos out'],
+       1: ['M item setup', 'M margin read', 'M hull rescans', 'M mpr call', 'M result stores', '(x31)'],
+       2: ['c1 pair reads + sphere tests', 'c1 ballot compaction', 'c2 box cull', 'c2 item compaction', 'C geom placement*', '(x31)'],
+       3: ['bb item list', 'bb item geoms', 'bb face axes', 'bb edge axes', 'bb clips', '(x31)'],
+       4: ['B link loop', 'B ancestors -> M', 'B qfrc + sync', 'B mirror + rows', '(x30)', '(x31)'],
+       5: ['E1 limits', 'E3 global reads', 'E3 frames / impedance', 'E3 link masks + sync / E5 aref', 'E5 cached Jacobian', '(x31)'],
+       6: ['F0 cost at qacc_smooth', 'F0 eval at warm start', '(x28)', '(x29)', '(x30)', '(x31)'],
+       7: ['H init', 'H cached contacts', 'H further contacts', 'H transposition', '(x30)', '(x31)']}
+sub = int(os.environ.get('HSR_SUBPROF', '0'))
+names += [f'x{26 + i} {n}' for i, n in enumerate(SUB[sub])]
+if sub:
+    print(f'HSR_SUBPROF={sub}: stamps 26..31 sit inside another phase - the time up to the first of them is charged to it, the parent phase keeps what follows the last')
 ph = a[:, 8:40].astype(np.float64) / 300.0
 slow, med = o[-20:], o[nb // 2 - 10: nb // 2 + 10]
 print('phase cycles per substep: slowest 20 blocks vs 20 median blocks')
