@@ -193,7 +193,7 @@ def _apply_setters(root, set_xml):
 
 
 def _parse_tree(ref_root: Path, xml_file: str, dofs: Sequence[str], n_blocks: int,
-                block_pos: np.ndarray, set_xml=()):
+                block_pos: np.ndarray, set_xml=(), block_geom=None):
     xml_path = ref_root / xml_file
     root = ET.parse(xml_path).getroot()
     meta = {}
@@ -203,9 +203,12 @@ def _parse_tree(ref_root: Path, xml_file: str, dofs: Sequence[str], n_blocks: in
         name = f"block{i}"
         body = ET.SubElement(worldbody, "body",
                              attrib=dict(name=name, pos=" ".join(repr(float(x)) for x in block_pos[i])))
-        ET.SubElement(body, "geom", attrib=dict(name=name, type="box", mass="1",
-                                                size=".05 .025 .017", condim="6",
-                                                solimp="0.99 0.99 0.01", solref="0.01 1"))
+        gattr = dict(name=name, type="box", mass="1", size=".05 .025 .017", condim="6", solimp="0.99 0.99 0.01", solref="0.01 1")
+        if block_geom:              # test scenes only: another shape for the injected body (e.g. one of the robot's hulls as a free body)
+            gattr.update(block_geom)
+            if gattr.get("type") == "mesh":
+                gattr.pop("size", None)
+        ET.SubElement(body, "geom", attrib=gattr)
         ET.SubElement(body, "freejoint", attrib=dict(name=f"block{i}joint"))
     _apply_setters(root, set_xml)
 
@@ -549,20 +552,27 @@ def mass_matrix(m: Model, qpos):
 # ----------------------------------------------------------------------------- compile
 def compile_model(dofs: Sequence[str] = ("slide_x", "slide_y"), n_blocks: int = 0,
                   block_pos: Optional[np.ndarray] = None, xml_file: str = "models/world.xml",
-                  ref_root: Path = DEFAULT_REF_ROOT, set_xml: Sequence = ()) -> Model:
+                  ref_root: Path = DEFAULT_REF_ROOT, set_xml: Sequence = (), block_geom: Optional[dict] = None,
+                  plane_convex_points: int = 1) -> Model:
+    """plane_convex_points: contacts a plane <-> convex (mesh / cylinder) pair may hold - 1: the deepest support point only (the committed
+    reference configurations); 4: up to three more around it, as MuJoCo's mjc_PlaneConvex adds them (oracle/hsr_oracle.c)."""
     ref_root = Path(ref_root)
+    assert plane_convex_points in (1, 4)
     if block_pos is None:
         # resting height on the pan: 0.405 + 0.017 (world.xml:83-84, util.py:120)
         block_pos = np.array([[0.0, 0.12 * (i - (n_blocks - 1) / 2.0), 0.422]
                               for i in range(n_blocks)]).reshape(n_blocks, 3)
     block_pos = np.asarray(block_pos, dtype=np.float64).reshape(n_blocks, 3)
     set_xml = [(str(p), str(v)) for p, v in set_xml]
-    parsed = _parse_tree(ref_root, xml_file, list(dofs), n_blocks, block_pos, set_xml)
+    parsed = _parse_tree(ref_root, xml_file, list(dofs), n_blocks, block_pos, set_xml, block_geom)
     bodies: List[_Body] = parsed["bodies"]
     opt = parsed["opt"]
     meta = dict(parsed["meta"])
     if set_xml:
         meta.update(set_xml=[list(c) for c in set_xml])
+    meta.update(plane_convex_points=int(plane_convex_points))
+    if block_geom:
+        meta.update(block_geom=dict(block_geom))
     meta.update(dofs=list(dofs), n_blocks=n_blocks, xml_file=xml_file,
                 decisions="H1 malformed pos->0; H2 inertiafromgeom all geoms density 1000 (legacy "
                           "mesh inertia); H3 default class 'all' is global; H4 hinge ranges in "
@@ -783,7 +793,7 @@ def compile_model(dofs: Sequence[str] = ("slide_x", "slide_y"), n_blocks: int = 
     npair = len(pairs)
     slot = np.zeros(npair + 1, dtype=np.int32)
     for i, p in enumerate(pairs):
-        slot[i + 1] = slot[i] + FN_MAXCON[p["fn"]]
+        slot[i + 1] = slot[i] + (plane_convex_points if p["fn"] == FN_PLANE_CONVEX else FN_MAXCON[p["fn"]])
 
     # ---- actuators -------------------------------------------------------------------------------------------------
     acts = parsed["actuators"]
@@ -949,6 +959,12 @@ TEST_CONFIGS = {
     # no robot dof at all: the robot is scenery (15 static hulls + the wrist cylinder), the block the only body - thrown around it, it
     # leaves and re-enters the cull ranges of the hulls (the separation-margin stamps of the convex pairs: tests/test_gpu_hotpath.py)
     "static1": dict(dofs=[], n_blocks=1),
+    # plane <-> convex with several points (round 4): the head-pan hull (32 vertices, a flat bottom face of 61 cm^2) as a free body lying on
+    # the FLOOR plane, away from the robot; the same scene with the single deepest point for comparison (tests/test_kat.py)
+    "meshrest4": dict(dofs=[], n_blocks=1, block_geom=dict(type="mesh", mesh="head_pan"), plane_convex_points=4,
+                      block_pos=np.array([[1.0, 0.6, 0.05]])),
+    "meshrest1": dict(dofs=[], n_blocks=1, block_geom=dict(type="mesh", mesh="head_pan"), plane_convex_points=1,
+                      block_pos=np.array([[1.0, 0.6, 0.05]])),
 }
 MODEL_DIR = Path(__file__).parent / "models"
 

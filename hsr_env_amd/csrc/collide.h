@@ -345,12 +345,38 @@ __device__ __forceinline__ void collide_plane_box(const Geom &P, const Geom &B, 
     }
 }
 
-// --- mjc_PlaneConvex restated with the deepest support point only
+// --- mjc_PlaneConvex: the deepest support point; when the pair has room for more (ContactOut::maxcnt: the compiler's plane_convex_points
+// = 4) up to three more - support points along -n tilted towards three tangent directions 120 degrees apart, kept when they lie below the
+// plane and are not a point already kept.  Restated from MuJoCo's behaviour; tilt and duplicate distance as in the oracle (oracle/hsr_oracle.c).
 __device__ __forceinline__ void collide_plane_convex(const Geom &P, const Geom &Cx, ContactOut &out) {
     const v3 n = col(P.mat, 2);
     const v3 p = support(Cx, -n);
     const float dist = dot(p - P.pos, n);
-    if (dist < 0) out.add(p - n * (0.5f * dist), n, dist);
+    if (!(dist < 0)) return;
+    out.add(p - n * (0.5f * dist), n, dist);
+    if (out.maxcnt <= 1) return;
+    v3 t1 = (n.y > -0.5f && n.y < 0.5f) ? mk3(0, 1, 0) : mk3(0, 0, 1);       // mju_makeFrame
+    t1 = normalized(t1 - n * dot(n, t1));
+    const v3 t2 = cross(n, t1);
+    v3 kept[4];
+    kept[0] = p;
+    int nk = 1;
+    const float cs[3][2] = {{1.f, 0.f}, {-0.5f, 0.8660254f}, {-0.5f, -0.8660254f}};
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        if (nk >= out.maxcnt) break;
+        const v3 q = support(Cx, (t1 * cs[i][0] + t2 * cs[i][1]) * 0.1f - n);
+        const float dq = dot(q - P.pos, n);
+        bool take = dq < 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) if (j < nk) { const v3 e = q - kept[j]; take = take && !(dot(e, e) < 1e-10f); }
+        if (take) {
+            out.add(q - n * (0.5f * dq), n, dq);
+#pragma unroll
+            for (int j = 1; j < 4; j++) if (j == nk) kept[j] = q;
+            nk++;
+        }
+    }
 }
 
 // --- box-box: SAT + reference-face clipping; polygon scratch lives in LDS ([buf][vertex][xyz][lane])

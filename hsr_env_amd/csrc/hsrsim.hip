@@ -250,6 +250,9 @@ struct hsr_batch {
     int slots = 0;                 // workgroups of the persistent kernel the GPU holds at once (occupancy x compute units)
     int queue = -1;                // work queue of the persistent kernel: -1 = automatic (on when there are more tasks than slots), 0 / 1 forced (HSR_QUEUE)
     int queue_chunk = 20;          // substeps per round of the work queue (HSR_QUEUE_CHUNK)
+    int solo_servers = 0;          // workgroups of a queued launch that run hard envs alone (persist.h; hsr_batch_set_solo / HSR_SOLO); 0 = off
+    float solo_trips = 3.5f;       // hand-over threshold: Newton iterations per substep over a round
+    bool solo_ok = false;          // the chosen kernel instance has the server path
     bool kernel_log = false;       // hsr_batch_set_profiling(b, 2): an event pair around every launch of the persistent kernel, no synchronisation
     std::vector<std::pair<hipEvent_t, hipEvent_t>> klog;
 };
@@ -655,7 +658,12 @@ static int batch_init(hsr_batch *b, const hsr_model *m, int n_envs) {
         if ((rc = dalloc(b, &s.q_wpos, QUEUE_ROUNDS))) return rc;
         if ((rc = dalloc(b, &s.q_items, (size_t)QUEUE_ROUNDS * tasks))) return rc;
         if ((rc = dalloc(b, &s.q_err, 1))) return rc;
+        s.sq_cap = (int)N + 4096;
+        if ((rc = dalloc(b, &s.sq_items, (size_t)s.sq_cap))) return rc;
+        if ((rc = dalloc(b, &s.sq_ctl, 4))) return rc;
+        s.solo_servers = 0; s.solo_trips_x4 = 14; s.solo_min_left = 40;
         s.q_chunk = 0;
+        { const char *so = getenv("HSR_SOLO"); if (so) b->solo_servers = atoi(so); const char *st = getenv("HSR_SOLO_TRIPS"); if (st && atof(st) > 0) b->solo_trips = (float)atof(st); }
         const char *q = getenv("HSR_QUEUE"); if (q) b->queue = atoi(q) != 0;
         const char *mw = getenv("HSR_MPR_WARM"); if (mw) b->mpr_warm = atoi(mw) != 0;
         const char *qc = getenv("HSR_QUEUE_CHUNK"); if (qc && atoi(qc) > 0) b->queue_chunk = atoi(qc);
@@ -732,6 +740,7 @@ static int batch_init(hsr_batch *b, const hsr_model *m, int n_envs) {
         if (ok && b->persist_lds_bytes > 48 * 1024)
             HIPCHK(hipFuncSetAttribute((const void *)persist_kernel(d, b->group, b->persist_tg), hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->persist_lds_bytes));
     }
+    b->solo_ok = b->persist_ok && b->group == 16 && cfg_const_row(d) >= 0;          // HAS_SOLO of persist.h: the instances of the reference configurations
     if (b->persist_ok) {
         int pb = 0;
         hipDeviceProp_t prop;
@@ -830,6 +839,20 @@ extern "C" int hsr_batch_set_mpr_warm(hsr_batch *b, int on) {
     if ((on != 0) != b->mpr_warm) clear_margins(b);
     b->mpr_warm = on != 0;
     return HSR_OK;
+}
+extern "C" int hsr_batch_set_solo(hsr_batch *b, int servers, float trips) {
+    NULLCHK(b);
+    if (servers < 0 || trips < 0.f) return fail(HSR_EINVAL, "hsr_batch_set_solo: servers >= 0, trips >= 0");
+    b->solo_servers = servers;
+    if (trips > 0.f) b->solo_trips = trips;
+    return b->solo_ok ? HSR_OK : 1;          // 1: accepted, but this model's kernel instance has no server path (the setting has no effect)
+}
+extern "C" int hsr_batch_solo_handovers(hsr_batch *b, int *out) {
+    if (!b || !out) return fail(HSR_EINVAL, "null argument");
+    HIPCHK(hipSetDevice(b->device));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    HIPCHK(hipMemcpy(out, b->ds.sq_ctl + 1, sizeof(int), hipMemcpyDeviceToHost));
+    return queue_error(b);
 }
 extern "C" int hsr_batch_set_queue(hsr_batch *b, int mode, int chunk) {
     NULLCHK(b);
@@ -1006,6 +1029,8 @@ enum { SCHED_CHUNK = 8192 };
 __global__ void k_queue_init(DevState s, int T, int R) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < R) { s.q_head[i] = 0; s.q_wpos[i] = i == 0 ? T : 0; }
+    if (i < 4) s.sq_ctl[i] = i == 2 ? s.solo_servers : 0;          // tickets taken, items reserved, free servers, finished tasks
+    if (s.solo_servers > 0) for (int k = i; k < s.sq_cap; k += gridDim.x * blockDim.x) s.sq_items[k] = -1;
     // q_err is NOT cleared here: a trip stays on record until the host has read it (queue_error), however many launches were enqueued since
     if (i < R * T) s.q_items[i] = i < T ? i : -1;
 }
@@ -1070,12 +1095,16 @@ extern "C" int hsr_batch_step_dev(hsr_batch *b, const float *d_ctrl, int n_subst
         const int T = (N + epb - 1) / epb;
         int chunk = b->queue_chunk;
         while ((n_substeps + chunk - 1) / chunk > QUEUE_ROUNDS) chunk *= 2;
-        const bool qon = b->slots > 0 && n_substeps >= 2 * chunk && (b->queue == 1 || (b->queue < 0 && T > b->slots));
+        // solo servers need the queue (a hard env leaves its task at the end of a round) and the env -> slot table
+        const bool solo = b->solo_ok && b->solo_servers > 0 && b->solo_servers <= 4096 && sched && b->slots > 0 && n_substeps >= 3 * chunk && (T + b->solo_servers <= b->slots || 4 * b->solo_servers <= b->slots);
+        const bool qon = b->slots > 0 && n_substeps >= 2 * chunk && (solo || b->queue == 1 || (b->queue < 0 && T > b->slots));
         int grid = T;
+        dsl.solo_servers = 0;
         if (qon) {
             const int R = (n_substeps + chunk - 1) / chunk;
             dsl.q_chunk = chunk;
             grid = T < b->slots ? T : b->slots;
+            if (solo) { dsl.solo_servers = b->solo_servers; dsl.solo_trips_x4 = (int)(4.f * b->solo_trips + 0.5f); dsl.solo_min_left = 2 * chunk; grid = std::min(b->slots, T + b->solo_servers); }
             hipLaunchKernelGGL(k_queue_init, grid1((size_t)R * T), dim3(256), 0, st, dsl, T, R);
         }
         hipEvent_t k0 = nullptr, k1 = nullptr;
@@ -1227,6 +1256,11 @@ extern "C" int hsr_batch_block_times(hsr_batch *b, unsigned long long *out, int 
     HIPCHK(hipSetDevice(b->device));
     HIPCHK(hipStreamSynchronize(b->stream));
     if (nblocks > 8192) nblocks = 8192;
+    if (nblocks < 0) {          // lifetime build: the per-env stamps (solve_g.h ENV_STAMP), 2 x 8192 values
+        HIPCHK(hipMemcpy(out, b->ds.phase_cyc + 32 + 40 * 4096, (size_t)2 * 8192 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemset(b->ds.phase_cyc + 32 + 40 * 4096, 0, (size_t)2 * 8192 * sizeof(unsigned long long)));
+        return HSR_OK;
+    }
     HIPCHK(hipMemcpy(out, b->ds.phase_cyc + 32, (size_t)nblocks * 40 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return HSR_OK;
 }

@@ -77,6 +77,12 @@ struct DevState {
     // work queue of the persistent kernel (persist.h: q_claim / q_push); q_chunk = 0: off (one task per workgroup, the whole env-step)
     int q_chunk;
     int *q_head, *q_wpos, *q_items, *q_err;
+    // solo servers of the persistent kernel (persist.h): the first solo_servers workgroups of a queued launch take no tasks; they wait for
+    // envs that a worker has found hard (solo_trips or more Newton iterations per substep over a round) and run each of them ALONE in a wave
+    // to the end of the env-step.  sq_items[ticket] = env | first substep << 20 (-1 until pushed); sq_ctl = { tickets taken, items
+    // reserved, servers without an env, tasks that finished their last round }
+    int solo_servers, solo_trips_x4, solo_min_left, sq_cap;      // sq_cap = entries of sq_items: every env can be handed over once, every server holds one more ticket
+    int *sq_items, *sq_ctl;
     unsigned long long *capstat;     // [4] cap statistics (include/hsrsim.h: hsr_batch_cap_counts)
     unsigned long long *phase_cyc;   // diagnostic build only (HSR_PHASE_TIMING): per-phase cycle sums
 };

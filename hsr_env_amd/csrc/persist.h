@@ -95,6 +95,7 @@ __device__ __forceinline__ void q_push(const DevState &s, int T, int task, int r
         const int p = __hip_atomic_fetch_add(&s.q_wpos[round + 1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(s.q_items + (size_t)(round + 1) * T + p, task, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
+    if (threadIdx.x == 0 && last && s.sq_ctl) __hip_atomic_fetch_add(&s.sq_ctl[3], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);      // the solo servers leave when every task is through
 }
 
 // NVT: compile-time bound on nv (nv <= NVT <= G); the matrix loops of the solver run to NVT instead of G
@@ -125,13 +126,21 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
     // A task = the envs of one lane-group set (EPB envs) over a run of substeps.  Without the work queue (s.q_chunk == 0) there is one
     // task per workgroup: its blockIdx.x and the whole env-step.  With it (more tasks than resident workgroups: see q_claim) a
     // workgroup takes (task, round) tickets until none is left; the env state travels through the state arrays in between.
-    int task = blockIdx.x, q_round = 0, q_rlo = 0;
+    int task = s.q_chunk ? 0 : blockIdx.x, q_round = 0, q_rlo = 0;      // queued launches: tasks come from q_claim (the grid may hold more workgroups than there are tasks)
+    // SOLO (shadowed inside run_task): this workgroup runs ONE env, handed over by a worker that found it hard, in lane group 0 (solo server)
+    // REP: the other lane groups of a solo server run the same env as REPLICAS - the same instructions on the same values, each group
+    // with its own LDS region - and split what can be split: the contacts of the Newton Hessian / gradient go round the groups (one pass of
+    // the matrix core covers EPB contacts, the partial sums are added across the rows); the collision front end runs once (group 0's
+    // candidate pairs, one item list, the contact counts copied to the other groups)
+    constexpr bool SOLO = false, REP = false;
+    const int solo_env = -1;
+    (void)solo_env;
     // everything derived from the lane id is declared through this macro: once for the prologue, once per substep from a
     // laundered copy of the lane id (so that LLVM does not hoist ~100 loop-invariant addresses out of the substep loop and
     // then spill them), once for the epilogue
 #define PERSIST_LANE_VIEW(TID)                                                                                              \
     const int tid = (TID), g = tid / G, c = tid % G;                                                                         \
-    const int e_raw = s.slot_env ? s.slot_env[task * EPB + g] : task * EPB + g;                                              \
+    const int e_raw = SOLO ? ((REP || g == 0) ? solo_env : -1) : (s.slot_env ? s.slot_env[task * EPB + g] : task * EPB + g); \
     const bool in_range = e_raw >= 0 && e_raw < N;                                                                           \
     const int e = in_range ? e_raw : 0;                                                                                      \
     float *E = lds + (size_t)g * L.envf;                                                                                     \
@@ -217,14 +226,20 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
     const v3 goal_off = goal_body >= 0 ? ld3(m.body_pos, goal_body) : mk3(0, 0, 0);
     PHASE_T0();
 
-  for (;;) {      // task loop (a single pass without the work queue)
-    if (s.q_chunk) {
-        if (!q_claim(s, (N + EPB - 1) / EPB, (n_substeps + s.q_chunk - 1) / s.q_chunk, q_rlo, task, q_round)) break;
-    }
-    const int sub0 = s.q_chunk ? q_round * s.q_chunk : 0, sub1 = s.q_chunk ? min(n_substeps, sub0 + s.q_chunk) : n_substeps;
+  constexpr bool HAS_SOLO = EXACT && G == 16 && !std::is_same<MT, DevModel>::value;      // the instances of the reference configurations
+  // one run of substeps [sub0, sub1) of a task (the envs of one lane-group set) - or, SOLO, of the single env solo_env in lane group 0
+  auto run_task = [&](auto solo_c, const int sub0, const int sub1, const int solo_env) {
+    constexpr bool SOLO = decltype(solo_c)::value;
+#ifndef HSR_SOLO_NO_REPLICAS
+    constexpr bool REP = SOLO;
+#else
+    constexpr bool REP = false;
+#endif
+    (void)solo_env;
     const bool first_run = sub0 == 0, last_run = sub1 >= n_substeps;
     const bool fresh = io.ctrl != nullptr && first_run;       // HSREnv.step begins here: ctrl[:] = action, a fresh done flag (hsr/env.py:116,124)
     cap_con = cap_row = cap_item = nsub_run = own_trips = 0; bad_acc = trips_acc = 0; nsteps_e = 0;
+    int run_trips = 0;                                     // Newton iterations of this lane's env over this run (hand-over to a solo server)
     // Item list of the narrowphase, kept over several substeps (HSR_SKIN > 0): it is built from culls that ask "closer than HSR_SKIN"
     // instead of "touching", and holds until some geom of some env of the workgroup may have moved half of that since (upper bounds of
     // the moves, the ones the separation margins of the convex pairs use).  A pair that is not on the list was farther apart than the
@@ -421,7 +436,7 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
                             const v3 r = mk3(a2[q].x - a1[q].x, a2[q].y - a1[q].y, a2[q].z - a1[q].z);
                             const float dpl = dot(r, mk3(nn[q].x, nn[q].y, nn[q].z)), dsq = dot(r, r);
                             const bool hit = pk_fn(pk[q]) <= FN_PLANE_CONVEX ? dpl <= rad : dsq <= rad * rad;
-                            mybits |= (valid && p0 + q < m.npair && hit) ? 1u << q : 0u;
+                            mybits |= (valid && (!REP || g == 0) && p0 + q < m.npair && hit) ? 1u << q : 0u;
                         }
                         u = 0; pb += 8 * G;
                         PHASE_S(2, 26);
@@ -594,6 +609,10 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
         }
         __threadfence_block();       // contact records written to global by other lanes of this workgroup
         __syncthreads();
+        if constexpr (REP) {         // the narrowphase left the contact counts with group 0: every replica gets its copy
+            if (g > 0) for (int i = c; i < m.npair_pad / 4; i += G) reinterpret_cast<int *>(pcnt)[i] = reinterpret_cast<const int *>(lds + L.oCnt)[i];
+            wave_sync();
+        }
         if (dbg_store && valid) for (int p = c; p < m.npair; p += G) s.ncon_pair[(size_t)e * m.npair_pad + p] = pcnt[p];
         PHASE(17);
         // ---------------- S: dynamics + constraint solve + Euler (shared body)
@@ -656,6 +675,7 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
             if (wave_any(valid && reach)) list_ok = false;      // the items of an env that just finished leave the list
             trips_acc += newton_trips;
             if (valid && n_substeps - sub <= 100) own_trips += iter;
+            if (valid) run_trips += iter;
             wave_sync();
             PHASE(18);
         }
@@ -668,7 +688,7 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
         if (c < nq) s.qpos[(size_t)c * N + e] = qpos_c;
         if (isdof) { s.qvel[(size_t)c * N + e] = qvel_c; s.warm[(size_t)c * N + e] = warm_c; }
         const float bsum = gsum<G>((float)bad_acc);
-        if (c == 0) {
+        if (c == 0 && (!REP || g == 0)) {
             if (cap_con) atomicAdd(&s.capstat[0], (unsigned long long)cap_con);
             if (cap_row) atomicAdd(&s.capstat[1], (unsigned long long)cap_row);
             if (cap_item) atomicAdd(&s.capstat[2], (unsigned long long)cap_item);
@@ -694,11 +714,75 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
             if (io.reward) io.reward[e] = done ? 1.f : 0.f;
             if (io.done) io.done[e] = done ? 1 : 0;
             if (io.nsteps) io.nsteps[e] = s.nsteps[e];
+            ENV_STAMP(0, e, __builtin_amdgcn_s_memrealtime());
+        }
+    }
+    // Hand-over of a hard env to a solo server (queued launches with servers only): an env that needed solo_trips or more Newton iterations
+    // per substep over this round, is not finished and has enough substeps left leaves its task if a server is free - its state is in the
+    // state arrays (written above), its slot of the task is emptied, and the server's ticket gets the env and the substep to go on from.
+    if constexpr (!SOLO && HAS_SOLO) {
+        if (s.q_chunk && s.solo_servers > 0 && !last_run) {
+            const bool hard = in_range && !done && n_substeps - sub1 >= s.solo_min_left && 4 * run_trips >= s.solo_trips_x4 * (sub1 - sub0);
+            if (wave_any(hard)) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");      // every lane: what it wrote of the state is out before the ticket is filled
+                __builtin_amdgcn_wave_barrier();
+                if (hard && c == 0) {
+                    const int old = __hip_atomic_fetch_sub(&s.sq_ctl[2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (old > 0) {
+                        const int pos = __hip_atomic_fetch_add(&s.sq_ctl[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        s.slot_env[task * EPB + g] = -1;
+                        ENV_STAMP(1, e, (unsigned long long)sub1 | (__builtin_amdgcn_s_memrealtime() << 16));
+                        __hip_atomic_store(&s.sq_items[pos], e | (sub1 << 20), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                    } else __hip_atomic_fetch_add(&s.sq_ctl[2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
         }
     }
     }
+  };      // run_task
+  if (HAS_SOLO && s.q_chunk && s.solo_servers > 0 && (int)blockIdx.x < s.solo_servers) {
+    // ---------------- solo server: no tasks; one hard env at a time, alone in this wave, from the substep its worker left it at to the
+    // end of the env-step.  A server always holds exactly one ticket of the hand-over list; it leaves when every task has finished its
+    // last round (no worker can hand anything over any more) and its ticket is still empty.
+    if constexpr (HAS_SOLO) {
+      const int T = (N + EPB - 1) / EPB;
+      for (;;) {
+        int item = -1;
+        if (threadIdx.x == 0) {
+            const int h = __hip_atomic_fetch_add(&s.sq_ctl[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int spins = 0;
+            for (; h < s.sq_cap;) {          // (tickets never reach the capacity: one per hand-over - at most one per env - and one per server)
+                item = __hip_atomic_load(&s.sq_items[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (item >= 0) break;
+                if (__hip_atomic_load(&s.sq_ctl[3], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= T) {      // all tasks done: a last look, then leave
+                    item = __hip_atomic_load(&s.sq_items[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(32);
+                if (++spins > (1 << 22) || __hip_atomic_load(s.q_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+                    __hip_atomic_store(s.q_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+            }
+        }
+        item = __builtin_amdgcn_readfirstlane(item);
+        if (item < 0) break;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        run_task(std::true_type{}, item >> 20, n_substeps, item & 0xfffff);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __builtin_amdgcn_wave_barrier();
+        if (threadIdx.x == 0) __hip_atomic_fetch_add(&s.sq_ctl[2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // free again
+      }
+    }
+  } else
+  for (;;) {      // task loop (a single pass without the work queue)
+    if (s.q_chunk) {
+        if (!q_claim(s, (N + EPB - 1) / EPB, (n_substeps + s.q_chunk - 1) / s.q_chunk, q_rlo, task, q_round)) break;
+    }
+    const int sub0 = s.q_chunk ? q_round * s.q_chunk : 0, sub1 = s.q_chunk ? min(n_substeps, sub0 + s.q_chunk) : n_substeps;
+    run_task(std::false_type{}, sub0, sub1, -1);
     if (!s.q_chunk) break;
-    q_push(s, (N + EPB - 1) / EPB, task, q_round, last_run);
+    q_push(s, (N + EPB - 1) / EPB, task, q_round, sub1 >= n_substeps);
   }
     const int tid = tid0; (void)tid;
 #ifdef HSR_PHASE_TIMING

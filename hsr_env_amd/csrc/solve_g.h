@@ -34,6 +34,7 @@ __device__ __forceinline__ unsigned long long stamp_() {
     return t;
 }
 #define DBGCNT(i, v) do { dc_[i] += (v); } while (0)
+#define ENV_STAMP(slot, e, val) do {} while (0)
 // the 32 phase sums live in ONE vector register (lane i = phase i; 32-bit: a launch is < 2^32 cycles) - as scalars they took 64
 // SGPRs, which the register allocator spilled into the hot loops
 #define PHASE_T0() unsigned long long dc_[4] = {0, 0, 0, 0}; unsigned int pt_v_ = 0; const unsigned int pt_lane_ = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); unsigned long long t_prev_ = stamp_(); const unsigned long long t_first_ = t_prev_, r_first_ = __builtin_amdgcn_s_memrealtime()
@@ -46,8 +47,12 @@ __device__ __forceinline__ unsigned long long stamp_() {
 #define DBGCNT(i, v) do { dc_[i] += (v); } while (0)
 #define PHASE(idx) do {} while (0)
 #define PHASE_FLUSH() do { if (tid == 0 && blockIdx.x < 8192) { unsigned long long *bt_ = s.phase_cyc + 32 + 40 * blockIdx.x; bt_[0] = r_first_; bt_[1] = __builtin_amdgcn_s_memrealtime(); bt_[4] = dc_[0]; bt_[5] = dc_[1]; bt_[6] = dc_[2]; bt_[7] = dc_[3]; } } while (0)
+// per-env stamps of the lifetime build (batches of up to 8192 envs, behind the records of 4096 workgroups): [0] when the env's env-step was
+// complete (100 MHz clock), [1] the substep at which it was handed over to a solo server (0: never) with the time of the hand-over above bit 16
+#define ENV_STAMP(slot, e, val) do { if ((e) < 8192) s.phase_cyc[32 + 40 * 4096 + 8192 * (slot) + (e)] = (val); } while (0)
 #else
 #define PHASE_T0() do {} while (0)
+#define ENV_STAMP(slot, e, val) do {} while (0)
 #define DBGCNT(i, v) do {} while (0)
 #define PHASE(idx) do {} while (0)
 #define PHASE_FLUSH() do {} while (0)

@@ -36,7 +36,7 @@ EXPORTS = [
     "hsr_batch_set_warmstart", "hsr_batch_get_warmstart", "hsr_batch_forward", "hsr_batch_step",
     "hsr_batch_step_dev", "hsr_batch_body_xpos", "hsr_batch_bad_state", "hsr_batch_get_field",
     "hsr_batch_set_profiling", "hsr_batch_last_timing", "hsr_batch_set_graph", "hsr_batch_set_persistent", "hsr_batch_is_persistent",
-    "hsr_batch_obs_openai", "hsr_batch_obs_openai_dev", "hsr_batch_set_debug", "hsr_batch_cap_counts", "hsr_batch_cap_histogram", "hsr_batch_newton_trips", "hsr_batch_set_schedule", "hsr_batch_set_goals",
+    "hsr_batch_obs_openai", "hsr_batch_obs_openai_dev", "hsr_batch_set_debug", "hsr_batch_cap_counts", "hsr_batch_cap_histogram", "hsr_batch_newton_trips", "hsr_batch_set_schedule", "hsr_batch_set_solo", "hsr_batch_solo_handovers", "hsr_batch_set_goals",
     "hsr_batch_phase_cycles", "hsr_batch_block_times", "hsr_batch_kernel_times", "hsr_batch_set_queue", "hsr_batch_set_mpr_warm",
 ]
 
@@ -99,6 +99,8 @@ def load_library():
     L.hsr_batch_cap_counts.argtypes = [vp, C.POINTER(C.c_ulonglong)]
     L.hsr_batch_cap_histogram.argtypes = [vp, C.POINTER(C.c_ulonglong)]
     L.hsr_batch_newton_trips.argtypes = [vp, C.POINTER(C.c_int32)]
+    L.hsr_batch_set_solo.argtypes = [vp, C.c_int, C.c_float]
+    L.hsr_batch_solo_handovers.argtypes = [vp, C.POINTER(C.c_int)]
     _lib = L
     return L
 
@@ -293,6 +295,20 @@ class BatchSim:
         a = (C.c_int * max(n, 1))(*[int(t[0]) for t in terms]); b = (C.c_int * max(n, 1))(*[int(t[1]) for t in terms])
         d = (C.c_float * max(n, 1))(*[float(t[2]) for t in terms])
         _check(self._L, self._L.hsr_batch_set_goals(self._b, n, a, b, d))
+
+    def set_solo(self, servers: int, trips: float = 0.0) -> bool:
+        """Solo servers of the persistent kernel (include/hsrsim.h): `servers` workgroups run hard envs alone; 0 = off.  Never changes a
+        result.  False when the model's kernel instance has no server path."""
+        rc = self._L.hsr_batch_set_solo(self._b, int(servers), float(trips))
+        if rc < 0:
+            _check(self._L, rc)
+        return rc == 0
+
+    def solo_handovers(self) -> int:
+        """Envs handed over to solo servers by the last step() (persistent kernel); synchronises."""
+        out = C.c_int(0)
+        _check(self._L, self._L.hsr_batch_solo_handovers(self._b, C.byref(out)))
+        return int(out.value)
 
     def set_schedule(self, on: bool):
         """Wave packing of the persistent kernel by env hardness (default on); never changes a result."""

@@ -133,6 +133,15 @@ int hsr_batch_is_persistent(const hsr_batch *b);
  * never served does): the flag is sticky on the device, the next synchronising call (hsr_batch_sync, _step, _kernel_times, _cap_counts,
  * _bad_state, _get_state) returns HSR_EDEVICE once and clears it. */
 int hsr_batch_set_debug(hsr_batch *b, int on);
+/* Solo servers of the persistent kernel (queued launches; the 16-lane instances of the reference configurations).  `servers` workgroups
+ * of the launch take no tasks: they wait for envs that a worker has found hard - `trips` or more Newton iterations per substep over a
+ * round of the work queue (0 keeps the current threshold) - and run each of them alone in a wave, from the substep its worker left it at to
+ * the end of the env-step, while the task it came from goes on without it.  The launch ends with its slowest env's chain (hsr/env.py:118-131
+ * is one serial loop per env); this shortens that chain.  0 servers = off.  A scheduling decision: an env's arithmetic does not depend
+ * on who runs it (results bit-identical with it on or off).  Returns 1 (not an error) when the model's kernel instance has no server path. */
+int hsr_batch_set_solo(hsr_batch *b, int servers, float trips);
+/* envs handed over to solo servers by the last persistent launch (synchronises) */
+int hsr_batch_solo_handovers(hsr_batch *b, int *out);
 /* wave packing of the persistent kernel (default on; HSR_SCHEDULE=0 turns it off at creation): before every launch the envs are re-distributed over the waves by the
  * Newton iterations they needed at the end of their previous launch (hard envs one per wave, with the easiest as neighbours).
  * A pure scheduling decision: every env's result is bit-identical with it on or off. */

@@ -520,14 +520,42 @@ static void support(const ho_model *m, const ho_data *d, int g, const double *di
     mulmv3(out, mat, loc); add3(out, out, pos);
 }
 
-/* mjc_PlaneConvex restated with the deepest support point only (1 contact) */
+/* mjc_PlaneConvex.  The deepest support point (direction -n) always; when the pair has room for more than one contact (pair_slot: the
+ * compiler's plane_convex_points = 4) up to three more, as MuJoCo adds them: support points along -n tilted towards three tangent
+ * directions 120 degrees apart, kept when they lie below the plane and are not one of the points already kept.  MuJoCo's source is not at
+ * hand: the scheme is restated from its behaviour, the tilt (0.1) and the duplicate distance (1e-5 m) are this restatement's own constants
+ * (deviations).  A hull resting on a flat face gets the extreme vertices of that face; a hull tilted by more than the tilt
+ * angle, or a rounded one, keeps the single point. */
+#define PLANE_CONVEX_TILT 0.1
+#define PLANE_CONVEX_DUP 1e-5
 static void collide_plane_convex(const ho_model *m, ho_data *d, int pair, int g1, int g2) {
     const double *pp = d->gpos + 3*g1, *pm = d->gmat + 9*g1;
     double n[3] = { pm[2], pm[5], pm[8] }, nn[3] = { -pm[2], -pm[5], -pm[8] }, p[3], r[3];
     support(m, d, g2, nn, p);
     sub3(r, p, pp);
     double dist = dot3(r, n);
-    if (dist < 0) { double pos[3]; copy3(pos, p); addscl3(pos, n, -0.5*dist); add_contact(m, d, pair, pos, n, dist); }
+    if (!(dist < 0)) return;
+    { double pos[3]; copy3(pos, p); addscl3(pos, n, -0.5*dist); add_contact(m, d, pair, pos, n, dist); }
+    const int maxcnt = m->pair_slot[pair+1] - m->pair_slot[pair];
+    if (maxcnt <= 1) return;
+    double fr[9], kept[4][3]; int nk = 1;
+    copy3(fr, n); make_frame(fr);
+    copy3(kept[0], p);
+    static const double cs[3][2] = { {1.0, 0.0}, {-0.5, 0.8660254037844386}, {-0.5, -0.8660254037844386} };
+    for (int i = 0; i < 3 && nk < maxcnt; i++) {
+        double dir[3], q[3];
+        for (int k = 0; k < 3; k++) dir[k] = nn[k] + PLANE_CONVEX_TILT * (cs[i][0]*fr[3+k] + cs[i][1]*fr[6+k]);
+        support(m, d, g2, dir, q);
+        sub3(r, q, pp);
+        const double dq = dot3(r, n);
+        if (!(dq < 0)) continue;
+        int dup = 0;
+        for (int j = 0; j < nk; j++) { double e[3]; sub3(e, q, kept[j]); if (dot3(e, e) < PLANE_CONVEX_DUP*PLANE_CONVEX_DUP) dup = 1; }
+        if (dup) continue;
+        double pos[3]; copy3(pos, q); addscl3(pos, n, -0.5*dq);
+        add_contact(m, d, pair, pos, n, dq);
+        copy3(kept[nk++], q);
+    }
 }
 
 /* --- box-box: separating-axis test + reference-face clipping (up to 8 points) */

@@ -15,4 +15,4 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def models():
     from hsr_env_amd.compiler import load_config
-    return {k: load_config(k) for k in ("cfg1", "cfg2", "cfg3", "cfg4", "cupboard", "cfg3_setxml", "nq18", "nv11", "nv23", "static1")}
+    return {k: load_config(k) for k in ("cfg1", "cfg2", "cfg3", "cfg4", "cupboard", "cfg3_setxml", "nq18", "nv11", "nv23", "static1", "meshrest4", "meshrest1")}

@@ -935,3 +935,138 @@ def test_full_size_invariants(models, cfg, n):
         errs.append(np.abs(full[0][0][e] - np.concatenate([o.qpos, o.qvel])).max())
     print(f"{cfg} x {n}: |dobs| vs the oracle after the first env-step, {len(errs)} envs: {np.array2string(np.array(errs), precision=1)}")
     assert len(errs) >= 1 and np.median(errs) < 1e-4, errs
+
+
+@pytest.mark.parametrize("cfg", ["cfg2", "cfg3", "cupboard"])
+def test_solo_servers_follow_the_plain_run(models, cfg):
+    """Round 4: hard envs leave their task at the end of a round of the work queue and a solo server runs them alone in a wave to the end
+    of the env-step, the wave's other lane groups as replicas that share out the contacts of the Newton Hessian / gradient (persist.h;
+    hsr_batch_set_solo).  With a threshold that every env passes and a server for each env the WHOLE batch is handed over after its
+    first round.  The replicas change the summation order of the Hessian and of J^T f, nothing else: against the run without servers the
+    env-step bookkeeping (time, substeps run) is identical, the finished envs are the same up to a goal test at the edge, and the states
+    agree like two fp32 summation orders do over 90 contact-rich substeps (median |dobs| < 1e-5, 90 % < 2e-3)."""
+    m = models[cfg]
+    n = 330
+    rng = np.random.default_rng(51)
+    q, v, ctrl = random_states(m, n, rng)
+    goal = np.tile([0.0, 0.0, 0.422], (n, 1)).astype(np.float32)
+    res = []
+    for servers in (0, n):
+        sim = hs.BatchSim(m, n)
+        assert sim.set_solo(servers, 0.01)
+        sim.set_queue(1, 10)
+        sim.set_mocap(goal)
+        sim.set_state(np.zeros(n), q, v)
+        obs, rew, done, ns = sim.step(ctrl, 90, m.body_id(m.block_body()), 0.1)
+        t, qq, vv = sim.get_state()
+        res.append((obs, rew, np.asarray(done, bool), ns, t))
+        assert not sim.bad_state()[1]
+        if servers:
+            ho = sim.solo_handovers()
+            assert ho >= (~res[0][2]).sum() * 0.9, f"{ho} envs handed over: the case must hand (nearly) every unfinished env over"
+        sim.close()
+    (o0, r0, d0, n0, t0), (o1, r1, d1, n1, t1) = res
+    assert 0 < d0.sum() < n, "the case needs early exits and full env-steps"
+    same = (d0 == d1) & (n0 == n1)
+    assert same.mean() >= 0.99, f"{(~same).sum()} envs finish differently"
+    assert np.array_equal(t0[same], t1[same]) and np.array_equal(r0[same], r1[same])
+    err = np.abs(o0[same] - o1[same]).max(1)
+    print(f"{cfg}: solo servers vs plain run over 90 substeps: |dobs| median {np.median(err):.2e}, 90 % {np.percentile(err, 90):.2e}, max {err.max():.2e}; {(~same).sum()} envs finish differently")
+    assert np.median(err) < 1e-5 and np.percentile(err, 90) < 2e-3
+
+
+@pytest.mark.parametrize("cfg", ["meshrest4", "meshrest1"])
+def test_plane_convex_contacts_match_oracle(models, cfg):
+    """Plane <-> convex (round 4: several points per pair in meshrest4, the deepest one only in meshrest1): the head-pan hull dropped on the
+    floor plane from 64 small tilts and heights; after the oracle has let it land (120 substeps: some lie on the face, some stand on an
+    edge, some are in the air) the HIP path's contacts of the next substep must equal the oracle's contact for contact (depth 1e-5, normal
+    2e-3, position 2e-4; a contact with |depth| < 2e-6 may exist in one precision only) and the substep must land on the oracle's
+    (|dqpos| < 5e-6, |dqvel| < 1e-4 (1 + |qvel|)) wherever the contact lists agree."""
+    m = models[cfg]
+    n = 64
+    rng = np.random.default_rng(61)
+    q = np.tile(m.qpos0, (n, 1))
+    q[:, 2] += rng.uniform(0.0, 0.03, n)
+    ax = rng.normal(size=(n, 3)); ax /= np.linalg.norm(ax, axis=1, keepdims=True)
+    ang = rng.uniform(0, 0.35, n)
+    q[:, 3] = np.cos(ang / 2); q[:, 4:7] = ax * np.sin(ang / 2)[:, None]
+    v = np.zeros((n, m.nv)); v[:, 3:6] = rng.normal(size=(n, 3)) * 0.3
+    ctrl = np.zeros((n, m.nu))
+    pre = oracle_rollout(m, q, v, ctrl, 120)
+    q1 = np.array([s.qpos for s in pre]); v1 = np.array([s.qvel for s in pre]); w1 = np.array([s.qacc_warmstart for s in pre])
+    sim = hs.BatchSim(m, n)
+    sim.set_debug(True)
+    sim.set_warmstart(w1)
+    sim.set_state(np.zeros(n), q1, v1)
+    obs = sim.step(ctrl, 1)[0]
+    con = sim.get_field(hs.F_CONTACT)
+    edge, multi, touching = 0, 0, 0
+    for e in range(n):
+        o = OracleSim(m)
+        o.qpos[:] = q1[e]; o.qvel[:] = v1[e]; o.qacc_warmstart[:] = w1[e]
+        o.set_euler_rhs(True)
+        o.step()
+        oc = o.contacts()
+        touching += len(oc) > 0; multi += len(oc) > 1
+        why = contact_mismatch(m, con[e], oc)
+        if why is not None:
+            gc = con[e][con[e][:, 6] <= 0]
+            shallow = (len(oc) and np.abs(oc[:, 12]).min() < 2e-6) or (len(gc) and np.abs(gc[:, 6]).min() < 2e-6)
+            assert why.startswith("count") and shallow, (e, why)
+            edge += 1
+            continue
+        dq = np.abs(obs[e, :m.nq] - o.qpos).max(); dv = (np.abs(obs[e, m.nq:] - o.qvel) / (1 + np.abs(o.qvel))).max()
+        assert dq < 5e-6 and dv < 1e-4, (e, dq, dv)
+    print(f"{cfg}: {touching} of {n} hulls touch the floor, {multi} with more than one contact, {edge} edge-of-existence envs")
+    assert touching >= n // 2 and edge <= 2
+    assert (multi >= n // 4) if cfg == "meshrest4" else (multi == 0)
+    sim.close()
+
+
+def test_hull_of_256_vertices_keeps_its_portal_warm_start(models):
+    """Round-3 advisor: the portal warm start of MPR packed its vertex ids in 8 bits with 0xff as "no vertex".  The ids now take 12 bits
+    per shape (hulls are refused beyond 256 vertices: collide.h MAXMESHV).  The case: the left finger tip's hull re-listed with 224
+    interior points IN FRONT of its 32 vertices - the same convex body, but every vertex that can support now has an id in 224 .. 255,
+    the last one the old "no vertex" marker.  The pinch scene (blocks dropped between the fingers: penetrating mesh <-> box pairs that
+    persist) must come out bit for bit as with the original vertex list, warm start on, and with contacts on that finger."""
+    from hsr_env_amd.compiler import Model, SZ_NMESHVERT
+    m0 = models["cfg3"]
+    g = list(m0.names["geom"]).index("hand_l_distal_link:l_distal")
+    arrays = {k: np.array(v, copy=True) for k, v in m0.arrays.items()}
+    mv = arrays["mesh_vert"].reshape(-1, 3)
+    a0, n0 = int(arrays["geom_meshadr"][g]), int(arrays["geom_meshnum"][g])
+    hull = mv[a0:a0 + n0]
+    cen = hull.mean(0)
+    inner = np.concatenate([cen + s * (hull - cen) for s in (0.2, 0.3, 0.4, 0.5, 0.6, 0.7, 0.8)])[:256 - n0]
+    assert len(inner) == 256 - n0
+    arrays["mesh_vert"] = np.concatenate([mv, inner, hull]).reshape((-1, 3) if m0.arrays["mesh_vert"].ndim == 2 else (-1,))
+    arrays["geom_meshadr"][g] = len(mv); arrays["geom_meshnum"][g] = 256
+    arrays["sizes"][SZ_NMESHVERT] = len(mv) + 256
+    m1 = Model(arrays=arrays, names=m0.names, meta=m0.meta)
+    m1 = Model.from_bytes(m1.to_bytes())
+    n = 96
+    rng = np.random.default_rng(3)
+    q, v, ctrl = random_states(m0, n, rng)
+    bl, br = m0.body_id("hand_l_distal_link"), m0.body_id("hand_r_distal_link")
+    a = m0.free_joint_qadrs()[0]
+    for e in range(n):
+        o = OracleSim(m0); o.qpos[:] = q[e]; o.forward()
+        q[e, a:a + 3] = 0.5 * (o.body_xpos(bl) + o.body_xpos(br)) + rng.uniform(-0.01, 0.01, 3)
+        quat = rng.normal(size=4); q[e, a + 3:a + 7] = quat / np.linalg.norm(quat)
+    res = []
+    for m in (m0, m1):
+        sim = hs.BatchSim(m, n)
+        sim.set_debug(True)
+        sim.set_state(np.zeros(n), q, np.zeros_like(v))
+        out = []
+        for gap in (1, 8, 20):
+            obs = sim.step(ctrl, gap)[0]
+            out += [obs, sim.get_field(hs.F_CONTACT), sim.get_field(hs.F_NCON)]
+        res.append(out)
+        assert not sim.bad_state()[1]
+        sim.close()
+    p_finger = [p for p in range(m0.npair) if int(m0.arrays["pair_geom1"][p]) == g or int(m0.arrays["pair_geom2"][p]) == g]
+    slots = np.concatenate([np.arange(m0.pair_slot[p], m0.pair_slot[p + 1]) for p in p_finger])
+    assert (res[0][1][:, slots, 6] <= 0).sum() >= 10, "the case needs contacts on the re-listed hull"
+    for x, y in zip(*res):
+        assert np.array_equal(x, y)

@@ -105,3 +105,32 @@ def test_stacked_blocks_static_equilibrium(models):
         assert (used.sum(1) == 4).all()
         assert np.abs(-c[..., 6][used] - d).max() < 4e-7, (ga, gb, c[..., 6][used])
     sim.close()
+
+
+def test_hull_on_a_plane_rests_on_several_points(models):
+    """GPU twin of tests/test_kat.py::test_hull_on_a_plane_rests_on_several_points: the head-pan hull on the floor plane through the C-ABI.
+    meshrest4 (up to four points per plane <-> convex pair): at rest on its flat face - three or four contacts, |angular velocity| < 5e-3,
+    attitude and place kept; meshrest1 (deepest point only): one contact, rocking for ever.  Eight replicas of the env: all identical."""
+    res = {}
+    for name in ("meshrest4", "meshrest1"):
+        m = models[name]
+        n = 8
+        sim = hs.BatchSim(m, n)
+        sim.set_debug(True)
+        sim.reset(qpos0=np.tile(m.qpos0, (n, 1)))
+        ctrl = np.zeros((n, m.nu), np.float32)
+        sim.step(ctrl, 600)
+        wmax = np.zeros(n); ncon = []
+        for k in range(6):
+            obs = sim.step(ctrl, 100)[0]
+            wmax = np.maximum(wmax, np.linalg.norm(obs[:, m.nq + 3:m.nq + 6], axis=1))
+            ncon.append(sim.get_field(hs.F_NCON).copy())
+        assert not sim.bad_state()[1]
+        assert np.array_equal(obs, np.tile(obs[:1], (n, 1)))
+        res[name] = (wmax, np.array(ncon), obs, m)
+        sim.close()
+    wmax, ncon, obs, m = res["meshrest4"]
+    assert ncon.min() >= 3 and ncon.max() <= 4 and wmax.max() < 5e-3
+    assert np.abs(obs[:, 3:7] - m.qpos0[3:7]).max() < 1e-3 and np.abs(obs[:, :2] - m.qpos0[:2]).max() < 1e-4
+    wmax1, ncon1, _, _ = res["meshrest1"]
+    assert ncon1.max() == 1 and wmax1.min() > 0.1

@@ -222,22 +222,30 @@ def first_contact_divergence(m, q0, ctrl, nsub):
     return first, before, reason, big
 
 
-@pytest.mark.parametrize("cfg", ["cfg1", "cfg2", "cfg3", "cfg4", "cupboard"])
+@pytest.mark.parametrize("cfg", ["cfg1", "cfg2", "cfg3", "cfg4", "cupboard", "cfg3+solo", "cupboard+solo"])
 def test_env_step_300_matches_oracle(models, cfg):
-    """A whole env-step (300 substeps): median |dobs| < 1e-4, 90th percentile < 2e-3 (contact dynamics amplify fp32 rounding over
+    """(The "+solo" cases: the same with every env handed over to a solo server after ten substeps - the migration forced on every env.)
+    A whole env-step (300 substeps): median |dobs| < 1e-4, 90th percentile < 2e-3 (contact dynamics amplify fp32 rounding over
     300 steps; per-substep parity is the sharp test; in the cupboard scene a random ctrl drives the arm into the doors in a fifth of
     the envs, which is chaotic in either precision: there the percentile bound is on the 75th).  And no env beyond 2e-3 goes
     unexplained: both sides are replayed substep by substep and the env must show a substep at which the HIP contact LIST differs from
     the oracle's beyond the stage tolerances - a contact that exists in one precision only, or (flat finger face on a flat door: the
     single MPR point of a face-face pair is not unique) one whose position / normal / depth the two precisions place differently; from there
     on the two runs are different trajectories - with the two still within 2e-3 of each other up to that substep."""
+    solo = cfg.endswith("+solo")          # every env handed over to a solo server after the first round of the work queue (round 4)
+    cfg = cfg.split("+")[0]
     m = models[cfg]
     n = 64
     rng = np.random.default_rng(12)
     q, v, ctrl = random_states(m, n, rng)
     sim = hs.BatchSim(m, n)
+    if solo:
+        assert sim.set_solo(n, 0.01)
+        sim.set_queue(1, 10)
     sim.set_state(np.zeros(n), q, np.zeros_like(v))
     obs, rew, done, ns = sim.step(ctrl, 300)
+    if solo:
+        assert sim.solo_handovers() == n
     errs = []
     for e in range(n):
         o = OracleSim(m)

@@ -384,3 +384,34 @@ def test_stacked_blocks_static_equilibrium(models):
     assert abs(s.qpos[qa[0] + 2] - 0.422 + 2 * REST_DEPTH) < 1e-9 and abs(s.qpos[qa[1] + 2] - 0.456 + 4 * REST_DEPTH) < 1e-9
     fn = np.sort(s.efc()["force"][-72:].reshape(12, 6)[:, 0])          # normal forces of the twelve condim-6 contacts
     assert np.allclose(fn[:8], G / 4, rtol=1e-6) and np.allclose(fn[8:], G / 2, rtol=1e-6)      # m g / 4 (block 2, block 1 on 0), 2 m g / 4 (pan under the stack)
+
+
+def test_hull_on_a_plane_rests_on_several_points(models):
+    """Plane <-> convex with several contact points (round 4; oracle/hsr_oracle.c collide_plane_convex, MuJoCo's mjc_PlaneConvex restated):
+    the head-pan hull - a flat bottom face of 61 cm^2 - set on the floor plane as a free body.  With up to four points per pair
+    (meshrest4) it comes to rest ON that face: three or more contacts, angular velocity below 5e-3 rad/s, the attitude it was set down in
+    kept to 1e-3, no drift, and the contact forces carry its weight.  With the single deepest point (meshrest1: the restatement the
+    reference configurations are compiled with - none of their hulls ever touches the floor) the one contact hops between the vertices of
+    the face and the body rocks for ever (0.4-0.6 rad/s) and walks away - what the several points are for."""
+    out = {}
+    for name in ("meshrest4", "meshrest1"):
+        m = models[name]
+        o = OracleSim(m)
+        o.qpos[:] = m.qpos0
+        wmax, ncon = 0.0, []
+        for k in range(1200):
+            o.step()
+            if k >= 600:
+                wmax = max(wmax, float(np.linalg.norm(o.qvel[3:])))
+                ncon.append(o.ncon)
+        out[name] = (wmax, ncon, np.array(o.qpos), np.array(o.efc()["force"]), m)
+    wmax, ncon, q, f, m = out["meshrest4"]
+    assert min(ncon) >= 3 and max(ncon) <= 4
+    assert wmax < 5e-3
+    assert np.abs(q[3:] - m.qpos0[3:]).max() < 1e-3 and np.abs(q[:2] - m.qpos0[:2]).max() < 1e-4
+    # the normal rows (every 4th: the hull's condim is the robot default) carry the weight: mass x 9.81
+    mass = float(m.arrays["link_mass"][-1])
+    dim = int(m.arrays["pair_condim"][[p for p in range(m.npair) if m.arrays["pair_fn"][p] == 1 and m.arrays["pair_geom2"][p] == m.ngeom - 1][0]])
+    assert abs(f[::dim].sum() - mass * 9.81) < 1e-2 * mass * 9.81          # (the body still creeps at the 1e-3 rad/s level)
+    wmax1, ncon1, q1, _, _ = out["meshrest1"]
+    assert max(ncon1) == 1 and wmax1 > 0.1, "the single-point restatement is expected to rock on a flat face"
