@@ -286,6 +286,22 @@ static int cfg_const_row(const DevModel &d) {
     return -1;
 }
 enum { QUEUE_ROUNDS = 64 };
+// the instance with the solo-server path (persist.h SV) of the configurations that have one, else NULL
+static persist_fn persist_kernel_sv(const DevModel &d, int group, bool tg) {
+    const int row = cfg_const_row(d);
+    if (group != 16) return nullptr;
+#ifdef HSR_DEV_CFG3
+    return (!tg && row == 2) ? k_env_step_mf<16, 13, true, 7, false, DevModel_cfg3, true> : nullptr;
+#else
+    if (tg) return row == 4 ? k_env_step_mf<16, 13, true, -1, true, DevModel_cupboard, true> : nullptr;
+    switch (row) {
+    case 1: return k_env_step_mf<16, 8, true, 0, false, DevModel_cfg2, true>;
+    case 2: return k_env_step_mf<16, 13, true, 7, false, DevModel_cfg3, true>;
+    case 4: return k_env_step_mf<16, 13, true, -1, false, DevModel_cupboard, true>;
+    default: return nullptr;
+    }
+#endif
+}
 static persist_fn persist_kernel(const DevModel &d, int group, bool tg = false) {
     const int row = cfg_const_row(d);
     const int nv = d.nv;
@@ -740,7 +756,9 @@ static int batch_init(hsr_batch *b, const hsr_model *m, int n_envs) {
         if (ok && b->persist_lds_bytes > 48 * 1024)
             HIPCHK(hipFuncSetAttribute((const void *)persist_kernel(d, b->group, b->persist_tg), hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->persist_lds_bytes));
     }
-    b->solo_ok = b->persist_ok && b->group == 16 && cfg_const_row(d) >= 0;          // HAS_SOLO of persist.h: the instances of the reference configurations
+    b->solo_ok = b->persist_ok && persist_kernel_sv(d, b->group, b->persist_tg) != nullptr;          // an instance with the server path exists
+    if (b->solo_ok && b->persist_lds_bytes > 48 * 1024)
+        HIPCHK(hipFuncSetAttribute((const void *)persist_kernel_sv(d, b->group, b->persist_tg), hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->persist_lds_bytes));
     if (b->persist_ok) {
         int pb = 0;
         hipDeviceProp_t prop;
@@ -1109,7 +1127,7 @@ extern "C" int hsr_batch_step_dev(hsr_batch *b, const float *d_ctrl, int n_subst
         }
         hipEvent_t k0 = nullptr, k1 = nullptr;
         if (b->kernel_log) { hipEventCreate(&k0); hipEventCreate(&k1); hipEventRecord(k0, st); }
-        hipLaunchKernelGGL(persist_kernel(b->dm, b->group, b->persist_tg), dim3(grid), dim3(64), b->persist_lds_bytes, st, (const DevModel *)b->d_dm, dsl, n_substeps, goal_body, geofence, (b->debug_store ? 1 : 0) | (b->test_hooks & ~32) | (b->mpr_warm ? 0 : 8), io);
+        hipLaunchKernelGGL(dsl.solo_servers > 0 ? persist_kernel_sv(b->dm, b->group, b->persist_tg) : persist_kernel(b->dm, b->group, b->persist_tg), dim3(grid), dim3(64), b->persist_lds_bytes, st, (const DevModel *)b->d_dm, dsl, n_substeps, goal_body, geofence, (b->debug_store ? 1 : 0) | (b->test_hooks & ~32) | (b->mpr_warm ? 0 : 8), io);
         if ((b->test_hooks & 32) && b->ds.q_err) HIPCHK(hipMemsetD32Async((hipDeviceptr_t)b->ds.q_err, 1, 1, st));      // tests: what q_claim's watchdog does when a ticket is never served
         if (b->kernel_log) { hipEventRecord(k1, st); b->klog.push_back({k0, k1}); }
         if (b->profiling) { hipEvent_t ev; hipEventCreate(&ev); hipEventRecord(ev, st); b->kev.push_back(ev); }   // slots 0,1 empty; slot 2 = the persistent kernel

@@ -105,7 +105,9 @@ __device__ __forceinline__ void q_push(const DevState &s, int T, int task, int r
 // MT: DevModel, or a type derived from it whose static constexpr members HIDE the scalar fields of the model (sizes, solver
 // options) with the values of one compiled configuration (cfg_consts.h): `m.nlink` is then a literal, the LDS layout a set of
 // immediates, and no scalar load / SGPR is spent on any of them; hsr_batch_create checks the values against the loaded model
-template <int G, int NVT, bool EXACT, int NDT = -1, bool TG = false, class MT = DevModel>
+// SV: the instance carries the solo-server path (hsr_batch_set_solo): a second copy of the substep loop with its own register allocation; the
+// default instances are compiled without it, a launch with servers picks the SV one
+template <int G, int NVT, bool EXACT, int NDT = -1, bool TG = false, class MT = DevModel, bool SV = false>
 __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restrict__ mp, DevState s, int n_substeps, int goal_body, float geofence, int flags, StepIO io) {
     // the ~90 model fields stay in (constant-cached) memory and are read where they are used, instead of sitting in - and
     // spilling from - SGPRs for the whole launch
@@ -226,7 +228,7 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
     const v3 goal_off = goal_body >= 0 ? ld3(m.body_pos, goal_body) : mk3(0, 0, 0);
     PHASE_T0();
 
-  constexpr bool HAS_SOLO = EXACT && G == 16 && !std::is_same<MT, DevModel>::value;      // the instances of the reference configurations
+  constexpr bool HAS_SOLO = SV && EXACT && G == 16 && !std::is_same<MT, DevModel>::value;      // server instances of the reference configurations
   // one run of substeps [sub0, sub1) of a task (the envs of one lane-group set) - or, SOLO, of the single env solo_env in lane group 0
   auto run_task = [&](auto solo_c, const int sub0, const int sub1, const int solo_env) {
     constexpr bool SOLO = decltype(solo_c)::value;
@@ -633,8 +635,11 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
         const int nfb = (EXACT && G == 32) ? m.nfb : 0;
 #endif
         float *fbK = poly + (size_t)g * 28 * nfb;
-        float *lvbuf = reinterpret_cast<float *>(pcnt);       // the pair counts are consumed by the contact compaction (E2), before the first J v
-        const int lvcap = ((m.npair_pad + 3) / 4) / 6;
+        // per-link velocity fields of J v: the rows of the reference-acceleration / residual arrays (both live in the contact lanes' registers
+        // since round 3; 2 R floats) - three vectors side by side in the setup, one in the Newton loop.  (Until round 4 the scratch was the
+        // pair-count bytes: two link slots at cfg2's 47 pairs, so every robot <-> block contact there fell back to the per-contact products.)
+        float *lvbuf = rAref;
+        const int lvcap = (2 * R) / 18 < 8 ? (2 * R) / 18 : 8;
         {
 #define SOLVE_STORE_DIAG dbg_store
 #define SOLVE_COUNT_CAPS 1

@@ -37,3 +37,34 @@ def test_no_dpp_read_right_after_inline_asm_write(tmp_path):
                     bad.append((t, t2))
     assert n_asm > 100, "the hand-written DPP instructions were not found in the assembly"
     assert not bad, bad[:3]
+
+
+@pytest.mark.skipif(not shutil.which(HIPCC), reason="hipcc not available")
+def test_no_scratch_access_inside_the_newton_loop(tmp_path):
+    """Round-3 verdict: the persistent kernel spills (256 VGPRs; the launch-long per-lane constants are parked in scratch across the
+    collision phases) - but no spill may sit inside the Newton loop, the part of the substep that the hardest envs run six times over.
+    In the assembly of the cfg3 instance the Newton loop is delimited by its matrix-core instructions (the Hessian's v_mfma, twice:
+    the exact Hessian and the PSD-majorant retry) and runs on through the Cholesky (13 v_rsq pivots after each Hessian), the line search
+    and the evaluation up to the loop's back edge; no scratch_load / scratch_store may appear from the first v_mfma to 1500 instructions
+    past the last one (the iteration's tail is about 1300 instructions long), and the same for the instance with the solo-server path."""
+    out = tmp_path / "cfg3.s"
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-S", "--cuda-device-only", "-DHSR_DEV_CFG3",
+                           "-Wno-unused-result", "-Wno-unused-value", "-o", str(out), str(ROOT / "hsr_env_amd" / "csrc" / "hsrsim.hip")],
+                          stderr=subprocess.DEVNULL)
+    text = out.read_text()
+    kernels = re.findall(r"^(_Z13k_env_step_mf\w*DevModel_cfg3Lb[01]E\w+):[^\n]*\n(.*?)s_endpgm", text, flags=re.S | re.M)
+    assert len(kernels) == 2, [k[0] for k in kernels]
+    for name, body in kernels:
+        ins = [t.strip() for t in body.split("\n") if t.strip() and not t.strip().startswith((".", ";", "//")) and not t.strip().endswith(":")]
+        mf = [i for i, t in enumerate(ins) if t.startswith("v_mfma")]
+        assert len(mf) >= 12, (name, len(mf))
+        # one Newton loop per copy of the substep body (the server instance has two): split the matrix-core instructions into clusters
+        clusters, start = [], mf[0]
+        for a, b in zip(mf, mf[1:] + [None]):
+            if b is None or b - a > 4000:
+                clusters.append((start, a)); start = b
+        assert len(clusters) == (2 if name.endswith("Lb1EEvPK8DevModel8DevStateiifi6StepIO") else 1), (name, clusters)
+        for lo, hi in clusters:
+            region = ins[lo:hi + 1500]
+            bad = [t for t in region if t.startswith("scratch_")]
+            assert not bad, (name, len(bad), bad[:3])
