@@ -639,7 +639,7 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
         // since round 3; 2 R floats) - three vectors side by side in the setup, one in the Newton loop.  (Until round 4 the scratch was the
         // pair-count bytes: two link slots at cfg2's 47 pairs, so every robot <-> block contact there fell back to the per-contact products.)
         float *lvbuf = rAref;
-        const int lvcap = (2 * R) / 18 < 8 ? (2 * R) / 18 : 8;
+        const int lvcap = (2 * R) / 6 < 16 ? (2 * R) / 6 : 16;          // link slots of a single J v (one is the world's); the setup's three at once: lvcap3
         {
 #define SOLVE_STORE_DIAG dbg_store
 #define SOLVE_COUNT_CAPS 1

@@ -1059,20 +1059,15 @@ static void ho_solve(const ho_model *m, ho_data *d) {
         alpha = -dp / hp;
         /* phi' has kinks where a cone changes its zone: the 1-D Newton iteration can then hop between the two ends of its bracket for ever
          * (found in round 4 on the cupboard scene: 0.2575 <-> 0.4224 for all 50 iterations, the step accepted at the end RAISED the cost and
-         * the improvement test ended the solve unconverged).  A bracket that did not shrink over two evaluations is bisected. */
-        double width_prev = -1; int stuck = 0;
+         * the improvement test ended the solve unconverged).  From the sixth evaluation on every second step bisects the bracket (the HIP
+         * line search carries the same rule). */
         for (int it = 0; it < ls_maxit; it++) {
             ls_eval(d, jar, jv, alpha, g1, g2, &dp, &hp);
             if (fabs(dp) < gtol) break;
             if (dp < 0) lo = alpha; else hi = alpha;
             double nxt = alpha - dp / hp;
             if (!(nxt > lo) || (hi > 0 && !(nxt < hi))) nxt = hi > 0 ? 0.5*(lo + hi) : 2*alpha;
-            else if (hi > 0) {
-                const double width = hi - lo;
-                stuck = (width_prev > 0 && width >= 0.999*width_prev) ? stuck + 1 : 0;
-                width_prev = width;
-                if (stuck >= 2) { nxt = 0.5*(lo + hi); stuck = 0; }
-            }
+            else if (it >= 5 && (it & 1) && hi > 0) nxt = 0.5*(lo + hi);
             alpha = nxt;
         }
         if (alpha <= 0) break;
