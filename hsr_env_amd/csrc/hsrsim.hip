@@ -280,7 +280,7 @@ typedef void (*persist_fn)(const DevModel *, DevState, int, int, float, int, Ste
 static int cfg_const_row(const DevModel &d) {
     const char *nc = getenv("HSR_NO_CONST");
     if (nc && strcmp(nc, "0") != 0) return -1;
-    int iv[20]; float fv[7];
+    int iv[sizeof kCfgConsts[0].i / sizeof(int)]; float fv[sizeof kCfgConsts[0].f / sizeof(float)];
     cfg_const_values(d, iv, fv);
     for (size_t r = 0; r < sizeof kCfgConsts / sizeof kCfgConsts[0]; r++)
         if (memcmp(iv, kCfgConsts[r].i, sizeof iv) == 0 && memcmp(fv, kCfgConsts[r].f, sizeof fv) == 0) return (int)r;
@@ -647,6 +647,11 @@ static int batch_init(hsr_batch *b, const hsr_model *m, int n_envs) {
     if ((rc = upload_mats(b, &d.body_mat, m, "body_quat"))) return rc;
     d.any_damping = 0;
     { size_t cnt; const double *dmp = m->f64("dof_damping", &cnt); for (size_t i = 0; i < cnt; i++) if (dmp[i] > 0) d.any_damping = 1; }
+    d.solimp_general = 0;
+    for (const char *nm : {"dof_solimp", "pair_solimp"}) {
+        size_t cnt; const double *si = m->f64(nm, &cnt);
+        for (size_t i = 4; si && i < cnt; i += 5) { const double pw = si[i] < 1 ? 1 : si[i]; if (pw != 1 && pw != 2) d.solimp_general = 1; }
+    }
 
     DevState &s = b->ds;
     const size_t N = (size_t)n_envs;

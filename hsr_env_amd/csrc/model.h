@@ -12,6 +12,7 @@ struct DevModel {
     int nq, nv, nu, nlink, nbody, ngeom, npair, nslot, nconmax, njmax, nM, ndense;
     float timestep, impratio, gravz, tolerance, ls_tolerance, mpr_tolerance, meaninertia;
     int iterations, ls_iterations, mpr_iterations, any_damping;
+    int solimp_general;              // some solimp power is neither 1 nor 2 (mj_makeImpedance's powf arms are needed); 0 for every committed model
     const int *link_parent, *link_dofadr, *link_dofnum, *link_qposadr, *link_free;
     const float *link_pos, *link_mat, *link_mass, *link_com, *link_inertia;
     const int *link_dofmask, *link_depth;   // depth of a link in the kinematic tree (world = 0)

@@ -391,3 +391,6 @@ __device__ __forceinline__ void cone_dd(int /*dim*/, float mu, const float *fri,
 }
 
 enum { NLMAX = 16 };
+// does the kernel instance of model type T need mj_makeImpedance's powf arms?  The run-time DevModel: yes; a constant instance says (cfg_consts.h)
+template <class T, class = void> struct SolimpGeneral { static constexpr bool value = true; };
+template <class T> struct SolimpGeneral<T, std::enable_if_t<!std::is_same<T, DevModel>::value>> { static constexpr bool value = T::solimp_general != 0; };

@@ -1,3 +1,3 @@
 mkdir -p gpurun_out/r4
-for n in 1 7 5 4; do HSR_SUBPROF=$n HSR_LIB=$PWD/hsr_env_amd/var_p${n}_t.so timeout -k 10 120 python tools/block_times.py > gpurun_out/r4/c29_bt_p$n.log 2>&1; echo "== p$n"; grep "x2[6-9]\|x3[01]\|total\|C mpr\|F hess\|E1-2\|E3\|E4-5\|B/C" gpurun_out/r4/c29_bt_p$n.log; done
-timeout -k 10 300 python bench.py --envs-per-gpu 65536 --steps 4 --warmup 2 --no-cpu-baseline > gpurun_out/r4/c29_64k.log 2>&1; tail -1 gpurun_out/r4/c29_64k.log | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('65536 envs auto chunk', round(d['value']/1e3,1), 'ms', round(d['ms_per_step'],1))"
+timeout -k 10 600 python -m pytest tests -m gpu -q -x > gpurun_out/r4/c31_tests.log 2>&1; echo "rc=$?" >> gpurun_out/r4/c31_tests.log; tail -3 gpurun_out/r4/c31_tests.log
+timeout -k 10 600 bash tools/ab.sh v14 v13 > gpurun_out/r4/c31_ab.log 2>&1; cat gpurun_out/r4/c31_ab.log; grep "E1-2\|E3 \|total" gpurun_out/r4/ab_v14_bt.log
