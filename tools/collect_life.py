@@ -1,0 +1,13 @@
+"""Merge the per-configuration lifetime summaries of tools/block_life.py --json (gpurun_out/r4/block_life_<cfg>.json) into profiles/block_life.json.
+usage: python tools/collect_life.py <note>"""
+import json, sys
+from pathlib import Path
+root = Path(__file__).resolve().parents[1]
+out = {}
+for cfg in ("cfg1", "cfg2", "cfg3", "cfg4", "cupboard"):
+    f = root / "gpurun_out" / "r4" / f"block_life_{cfg}.json"
+    if f.exists():
+        out.update(json.loads(f.read_text()))
+out["_note"] = sys.argv[1] if len(sys.argv) > 1 else ""
+(root / "profiles" / "block_life.json").write_text(json.dumps(out, indent=1))
+print({k: (round(v["p50_ms"], 2), round(v["p100_ms"], 2), round(v["mean_over_p100"], 3)) for k, v in out.items() if isinstance(v, dict)})
