@@ -310,7 +310,7 @@ def main():
             pj = json.loads(pmc.read_text())
             traffic = pj.get(names[dom].split("<")[0], {}).get("hbm_bytes_per_launch")
             if traffic is not None:
-                traffic_source = ("profiles/pmc_summary.json (committed; rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --steps 1`, "
+                traffic_source = ("profiles/pmc_summary.json (committed; rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --steps 1 --warmup 3`, the fourth launch after a reset; "
                                   "not collected in this run): " + str(pj.get("_note", ""))[:160])
         except Exception:
             traffic = None

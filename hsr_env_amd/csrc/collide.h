@@ -273,10 +273,14 @@ template <int W = 1> __device__ __forceinline__ v3 support(const Geom &G, v3 dir
         const int sub = threadIdx.x & (W - 1);
         float b = -3.0e38f;
         int idx = 0x7fffffff;
+        // the sub-group scans are only used by the persistent kernel, whose hulls stay in global memory (kin2.h: geom_cached3): say so, or the
+        // loads are compiled as flat_load (generic address: both wait counters, the LDS aperture check)
+        const __attribute__((address_space(1))) float *gverts = (const __attribute__((address_space(1))) float *)G.verts;
+        auto gvert = [&](int i) { return make_float4(gverts[4 * i], gverts[4 * i + 1], gverts[4 * i + 2], 0.f); };
         for (int i0 = 0; i0 < G.nvert; i0 += 4 * W) {
             float4 q[4];
 #pragma unroll
-            for (int u = 0; u < 4; u++) { const int i = i0 + u * W + sub; q[u] = G.verts[i < G.nvert ? i : 0]; }
+            for (int u = 0; u < 4; u++) { const int i = i0 + u * W + sub; q[u] = gvert(i < G.nvert ? i : 0); }
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 const int i = i0 + u * W + sub;
@@ -288,7 +292,7 @@ template <int W = 1> __device__ __forceinline__ v3 support(const Geom &G, v3 dir
         if constexpr (W >= 4) sup_merge<W>(b, idx, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, b), 0x4E, 0xf, 0xf, false)), __builtin_amdgcn_update_dpp(0, idx, 0x4E, 0xf, 0xf, false));
         if constexpr (W >= 8) sup_merge<W>(b, idx, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, b), 0x141, 0xf, 0xf, false)), __builtin_amdgcn_update_dpp(0, idx, 0x141, 0xf, 0xf, false));
         if constexpr (W >= 16) sup_merge<W>(b, idx, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, b), 0x140, 0xf, 0xf, false)), __builtin_amdgcn_update_dpp(0, idx, 0x140, 0xf, 0xf, false));
-        const float4 w = G.verts[G.nvert > 0 ? idx : 0];
+        const float4 w = gvert(G.nvert > 0 ? idx : 0);
         loc = mk3(w.x, w.y, w.z);
         if (vid) *vid = G.nvert > 0 ? idx : 0;
       } else {
@@ -524,12 +528,18 @@ template <int Q> __device__ __forceinline__ int sg8_bcast(int v) { const int lo 
 template <int Q> __device__ __forceinline__ float sg8_bcast(float v) { return __builtin_bit_cast(float, sg8_bcast<Q>(__builtin_bit_cast(int, v))); }
 __device__ __forceinline__ float sg8_next(float v) { return dppf_<0x101>(v); }
 struct NoStamp { __device__ __forceinline__ void operator()(int) const {} };
-template <class ST = NoStamp> __device__ __forceinline__ int collide_box_box_w8(const Geom &G1, const Geom &G2, float *con, int slot, int maxcnt, volatile float *scr, ST stamp = ST()) {
+template <class ST = NoStamp> __device__ __forceinline__ int collide_box_box_w8(const Geom &G1, const Geom &G2, float *con, int slot, int maxcnt, float *scr, ST stamp = ST()) {
     const int sub = threadIdx.x & 7;
     v3 A[3], B[3];
     float s1[3] = {G1.size.x, G1.size.y, G1.size.z}, s2[3] = {G2.size.x, G2.size.y, G2.size.z};
 #pragma unroll
     for (int i = 0; i < 3; i++) { A[i] = col(G1.mat, i); B[i] = col(G2.mat, i); }
+    // opaque copies for the lane-dependent picks (`i == 0 ? A0 : ...`): written on the arrays themselves the picks come back from the optimiser as ONE
+    // load with a computed index - and an array indexed that way cannot stay in registers: both rotation matrices went to scratch memory and every
+    // substep of every workgroup paid a scratch store + dependent scratch loads for the block resting on the table
+    v3 A0 = A[0], A1 = A[1], A2 = A[2], B0 = B[0], B1 = B[1], B2 = B[2];
+    asm volatile("" : "+v"(A0.x), "+v"(A0.y), "+v"(A0.z), "+v"(A1.x), "+v"(A1.y), "+v"(A1.z), "+v"(A2.x), "+v"(A2.y), "+v"(A2.z));
+    asm volatile("" : "+v"(B0.x), "+v"(B0.y), "+v"(B0.z), "+v"(B1.x), "+v"(B1.y), "+v"(B1.z), "+v"(B2.x), "+v"(B2.y), "+v"(B2.z));
     const v3 dv = G2.pos - G1.pos;
     float aC[3][3];
 #pragma unroll
@@ -563,7 +573,7 @@ template <class ST = NoStamp> __device__ __forceinline__ int collide_box_box_w8(
 #pragma unroll
     for (int r = 0; r < 2; r++) {
         const int q = r == 0 ? sub : 8, i = q / 3, j = q - 3 * i;
-        const v3 Ai = i == 0 ? A[0] : (i == 1 ? A[1] : A[2]), Bj = j == 0 ? B[0] : (j == 1 ? B[1] : B[2]);
+        const v3 Ai = i == 0 ? A0 : (i == 1 ? A1 : A2), Bj = j == 0 ? B0 : (j == 1 ? B1 : B2);
         v3 L = cross(Ai, Bj);
         const float ln = norm(L);
         eok[r] = ln < 1e-6f ? 0 : 1;
@@ -684,8 +694,8 @@ template <class ST = NoStamp> __device__ __forceinline__ int collide_box_box_w8(
             if (k != i) pa = pa + A[k] * ((dot(bestn, A[k]) > 0 ? 1.f : -1.f) * s1[k]);
             if (k != j) pb = pb + B[k] * ((dot(bestn, B[k]) > 0 ? -1.f : 1.f) * s2[k]);
         }
-        const v3 Ai_ = i == 0 ? A[0] : (i == 1 ? A[1] : A[2]);
-        const v3 Bj_ = j == 0 ? B[0] : (j == 1 ? B[1] : B[2]);
+        const v3 Ai_ = i == 0 ? A0 : (i == 1 ? A1 : A2);
+        const v3 Bj_ = j == 0 ? B0 : (j == 1 ? B1 : B2);
         const v3 w = pa - pb;
         const float b = dot(Ai_, Bj_), dd = dot(Ai_, w), ee = dot(Bj_, w), den = 1.f - b * b;
         const float t = den > 1e-12f ? (b * ee - dd) / den : 0.f, uu = den > 1e-12f ? (ee - b * dd) / den : 0.f;

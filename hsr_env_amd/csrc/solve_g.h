@@ -38,7 +38,8 @@ __device__ __forceinline__ unsigned long long stamp_() {
 // the 32 phase sums live in ONE vector register (lane i = phase i; 32-bit: a launch is < 2^32 cycles) - as scalars they took 64
 // SGPRs, which the register allocator spilled into the hot loops
 #define PHASE_T0() unsigned long long dc_[4] = {0, 0, 0, 0}; unsigned int pt_v_ = 0; const unsigned int pt_lane_ = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); unsigned long long t_prev_ = stamp_(); const unsigned long long t_first_ = t_prev_, r_first_ = __builtin_amdgcn_s_memrealtime()
-#define PHASE(idx) do { const unsigned long long t_now_ = stamp_(); pt_v_ += (pt_lane_ == (unsigned)(idx)) ? (unsigned int)(t_now_ - t_prev_) : 0u; t_prev_ = t_now_; } while (0)
+// (v_readlane / v_writelane ignore EXEC: a stamp inside divergent code counts whichever lanes are active)
+#define PHASE(idx) do { const unsigned long long t_now_ = stamp_(); const unsigned int acc_ = (unsigned int)__builtin_amdgcn_readfirstlane((int)((unsigned int)__builtin_amdgcn_readlane((int)pt_v_, (idx)) + (unsigned int)(t_now_ - t_prev_))); asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(pt_v_) : "s"(acc_), "i"(idx)); t_prev_ = t_now_; } while (0)
 #define PHASE_FLUSH() do { if (blockIdx.x < 8192 && pt_lane_ < 32) { unsigned long long *bt_ = s.phase_cyc + 32 + 40 * blockIdx.x; bt_[8 + pt_lane_] = (unsigned long long)pt_v_; if (pt_lane_ < 26) atomicAdd(&s.phase_cyc[pt_lane_], (unsigned long long)pt_v_); } if (tid == 0) { if (blockIdx.x < 8192) { unsigned long long *bt_ = s.phase_cyc + 32 + 40 * blockIdx.x; bt_[4] = dc_[0]; bt_[5] = dc_[1]; bt_[6] = dc_[2]; bt_[7] = dc_[3]; bt_[0] = r_first_; bt_[1] = __builtin_amdgcn_s_memrealtime(); bt_[2] = __builtin_amdgcn_s_getreg(63492); bt_[3] = __builtin_amdgcn_s_getreg(63508); } atomicAdd(&s.phase_cyc[26], stamp_() - t_first_); atomicAdd(&s.phase_cyc[27], __builtin_amdgcn_s_memrealtime() - r_first_); } } while (0)
 #elif defined(HSR_BLOCK_LIFE)
 // second diagnostic build (libhsrsim_life.so, tools/block_life.py): only the (start, end) stamps of every workgroup and the event

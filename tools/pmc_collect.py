@@ -18,9 +18,14 @@ def counters(d):
     out = defaultdict(lambda: defaultdict(float)); launches = defaultdict(set)
     files = sorted(glob.glob(str(src / d / "*" / "*counter_collection.csv")), key=lambda f: Path(f).stat().st_mtime)
     for f in files[-1:]:            # gpurun merges every call's outputs into the same directory: the newest run only
-        for r in csv.DictReader(open(f)):
+        rows = list(csv.DictReader(open(f)))
+        # the persistent kernel: its LAST launch only (the PMC passes run three warm-up env-steps first: the launches right after a reset are short -
+        # nothing is in contact yet - and would flatter every per-launch figure)
+        last = max((int(r["Dispatch_Id"]) for r in rows if "k_env_step_mf" in r["Kernel_Name"]), default=-1)
+        for r in rows:
             k = r["Kernel_Name"].split("(")[0].split("<")[0]
             k = k[k.find("k_"):] if "k_" in k else k
+            if "k_env_step_mf" in k and int(r["Dispatch_Id"]) != last: continue
             out[k][r["Counter_Name"]] += float(r["Counter_Value"]); launches[k].add(r["Dispatch_Id"])
     return out, {k: len(v) for k, v in launches.items()}
 
@@ -42,8 +47,35 @@ for k, v in sq.items():
         summary["_sq_per_wave_per_substep"] = {c: round(x / n, 1) for c, x in sorted(v.items())}
         summary["_sq_per_wave_per_substep"]["note"] = (f"{tag}: SQ counters of k_env_step_mf divided by (launches x {waves} waves x {nsub} substeps); "
                                                        "*_CYCLES / ACTIVE / WAIT in units of 4 clocks")
+wr, nwr = counters("pmc_wr")
+for k, v in wr.items():
+    if "k_env_step_mf" in k and v.get("TCC_EA0_WRREQ_sum"):
+        n64, nall, l2w = v.get("TCC_EA0_WRREQ_64B_sum", 0.0), v["TCC_EA0_WRREQ_sum"], v.get("TCC_WRITE_sum", 0.0)
+        summary["_hbm_writes_of_k_env_step_mf"] = {
+            "write_requests_leaving_L2": nall, "of_them_full_64B_lines": n64, "bytes_full_lines": 64 * n64, "bytes_32B_partial": 32 * (nall - n64),
+            "write_requests_reaching_L2": l2w,
+            "reading": "one launch (the fourth after a reset).  The counters cannot name buffers; they separate two kinds.  Full 64 B lines are wave-wide rows: the "
+                       "register spills (scratch_store: 64 lanes x 4..16 B contiguous; 36 static stores in the cfg3 instance, 208 B per lane = 27 MB for the 2048 waves, "
+                       "about what the eight L2s hold, so spilled rows are evicted and come back) and the once-per-launch SoA outputs (obs / qpos / qvel / warm start: 3 MB).  "
+                       "32 B partial writes are single words of env-strided arrays - DevState::sepax / septick (separation margin + stamp of every convex item, "
+                       "two words per item and substep, 19 MB footprint), the per-pair contact counts - and the 32 B contact records (DevState::con, 2 x float4 per contact).  "
+                       "Requests reaching L2 against requests leaving it = how much of the store stream L2 absorbs."}
+# the kernel-stats CSV averages every launch of the trace run, warm-up included (the first launches after a reset are short: nothing is in
+# contact yet); what bench.py times are the last `--steps` launches: their mean from the same trace, next to the bench line's own figure
+try:
+    import re
+    tr = sorted(glob.glob(str(src / "trace" / "*" / "*kernel_trace.csv")), key=lambda f: Path(f).stat().st_mtime)[-1]
+    rows = sorted((r for r in csv.DictReader(open(tr)) if "k_env_step_mf" in r["Kernel_Name"]), key=lambda r: int(r["Start_Timestamp"]))
+    dur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in rows]
+    line = [l for l in open(src / "trace.log") if l.startswith("{")][-1]
+    b = json.loads(line)
+    k = b["steps"]
+    summary["_timed_launches"] = {"all_launches_ms": [round(x, 2) for x in dur], "timed": k, "mean_ms_of_the_timed_launches_rocprofv3": round(sum(dur[-k:]) / k, 3),
+                                  "mean_ms_bench_hip_events_same_run": round(b["roofline"]["kernel_ms_mean"], 3), "bench_value_same_run": round(b["value"], 1)}
+except Exception as ex:           # a missing trace is not an error of the PMC summary
+    summary["_timed_launches"] = {"error": str(ex)}
 summary["_note"] = (f"{tag}, commit {commit}{' + uncommitted changes' if dirty else ''}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_* in separate passes (with --kernel-trace only), python3 bench.py --steps 1 "
-                    "--warmup 0 --no-cpu-baseline (cfg3, 8192 envs); bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 per the gfx950 correction of "
+                    "--warmup 3 --no-cpu-baseline (cfg3, 8192 envs; k_env_step_mf: the fourth, timed launch only); bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 per the gfx950 correction of "
                     "MI355X_MICROARCH.md; k_env_step_mf: one launch = 300 substeps of 8192 envs (algorithmic 630 MB) including ctrl in and obs / reward / done out; narrow accesses are uncalibrated")
 (prof / "pmc_summary.json").write_text(json.dumps(summary, indent=1))
 print(json.dumps({k: summary[k] for k in summary if "env_step" in k or k.startswith("_sq")}, indent=1))
