@@ -932,6 +932,16 @@ extern "C" int hsr_batch_newton_trips(hsr_batch *b, int32_t *out) {
     HIPCHK(hipMemcpy(out, b->ds.trips, (size_t)b->N * sizeof(int32_t), hipMemcpyDeviceToHost));
     return HSR_OK;
 }
+// the packing the last persistent launch ran with: out[slot] = env of lane group `slot % (64 / group)` of task `slot / (64 / group)`, -1 = empty
+extern "C" int hsr_batch_packing(hsr_batch *b, int32_t *out) {
+    if (!b || !out) return fail(HSR_EINVAL, "null argument");
+    if (!b->persist || !b->schedule || !b->d_slot_env) return fail(HSR_EINVAL, "hsr_batch_packing: no packed persistent launch on this batch");
+    HIPCHK(hipSetDevice(b->device));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    const int epb = 64 / b->group, slots = (b->N + epb - 1) / epb * epb;
+    HIPCHK(hipMemcpy(out, b->d_slot_env, sizeof(int32_t) * slots, hipMemcpyDeviceToHost));
+    return queue_error(b);
+}
 
 // one substep of the per-substep chain = 4 launches on the batch stream (the persistent kernel needs none of them)
 static void launch_substep(hsr_batch *b, int mode, int goal_body, float geofence, int debug, hipStream_t st, bool timed) {
@@ -1058,26 +1068,59 @@ __global__ void k_queue_init(DevState s, int T, int R) {
     // q_err is NOT cleared here: a trip stays on record until the host has read it (queue_error), however many launches were enqueued since
     if (i < R * T) s.q_items[i] = i < T ? i : -1;
 }
+// The bitonic network with eight consecutive keys per thread in registers: exchanges at distance 1, 2, 4 stay inside the thread, 8 .. 256 inside
+// the wave (one shuffle per key), and only 512 .. 4096 cross waves through LDS - 10 of the 91 stages need a barrier (round 3: all 91, 124 us of
+// every env-step; the packing it computes saves 280 us of the cfg3 launch)
+template <int J> __device__ __forceinline__ void sched_local_stage(unsigned (&v)[8], int tid, int k) {
+    unsigned w[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const int i = 8 * tid + r;
+        const unsigned a = v[r], c = v[r ^ J];
+        w[r] = (((i & J) == 0) == ((i & k) == 0)) ? (a > c ? a : c) : (a < c ? a : c);     // the lower index of a descending pair keeps the larger key
+    }
+#pragma unroll
+    for (int r = 0; r < 8; r++) v[r] = w[r];
+}
 __global__ void __launch_bounds__(1024) k_schedule(DevState s, int epb, int *slot_env) {
     __shared__ unsigned key[SCHED_CHUNK];
+    const int tid = threadIdx.x;
     const int e0 = blockIdx.x * SCHED_CHUNK, n = min(SCHED_CHUNK, s.N - e0);
-    for (int i = threadIdx.x; i < SCHED_CHUNK; i += blockDim.x) {
+    unsigned v[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const int i = 8 * tid + r;
         const int t = i < n ? min(s.trips[e0 + i], 0x1fffe) : 0;
-        key[i] = i < n ? ((unsigned)(t + 1) << 13) | (unsigned)(SCHED_CHUNK - 1 - i) : 0u;       // descending: more iterations first, then lower index
+        v[r] = i < n ? ((unsigned)(t + 1) << 13) | (unsigned)(SCHED_CHUNK - 1 - i) : 0u;       // descending: more iterations first, then lower index
     }
-    __syncthreads();
-    for (int k = 2; k <= SCHED_CHUNK; k <<= 1)
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = threadIdx.x; i < SCHED_CHUNK; i += blockDim.x) {
-                const int x = i ^ j;
-                if (x > i) {
-                    const unsigned a = key[i], c = key[x];
-                    const bool desc = (i & k) == 0;
-                    if (desc ? a < c : a > c) { key[i] = c; key[x] = a; }
-                }
+    for (int k = 2; k <= SCHED_CHUNK; k <<= 1) {
+        for (int j = k >> 1; j >= 512; j >>= 1) {              // partner in another wave: keys laid out [register][thread], no bank conflicts
+#pragma unroll
+            for (int r = 0; r < 8; r++) key[1024 * r + tid] = v[r];
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const int i = 8 * tid + r;
+                const unsigned a = v[r], c = key[1024 * r + (tid ^ (j >> 3))];
+                v[r] = (((i & j) == 0) == ((i & k) == 0)) ? (a > c ? a : c) : (a < c ? a : c);
             }
             __syncthreads();
         }
+        for (int j = (k >> 1) < 256 ? (k >> 1) : 256; j >= 8; j >>= 1) {      // partner in the same wave
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const int i = 8 * tid + r;
+                const unsigned a = v[r], c = (unsigned)__shfl_xor((int)v[r], j >> 3, 64);
+                v[r] = (((i & j) == 0) == ((i & k) == 0)) ? (a > c ? a : c) : (a < c ? a : c);
+            }
+        }
+        if (k >= 8) sched_local_stage<4>(v, tid, k);
+        if (k >= 4) sched_local_stage<2>(v, tid, k);
+        sched_local_stage<1>(v, tid, k);
+    }
+#pragma unroll
+    for (int r = 0; r < 8; r++) key[8 * tid + r] = v[r];
+    __syncthreads();
     const int nw = (n + epb - 1) / epb;
     for (int sl = threadIdx.x; sl < nw * epb; sl += blockDim.x) {
         const int w = sl / epb, j = sl % epb;

@@ -36,7 +36,7 @@ EXPORTS = [
     "hsr_batch_set_warmstart", "hsr_batch_get_warmstart", "hsr_batch_forward", "hsr_batch_step",
     "hsr_batch_step_dev", "hsr_batch_body_xpos", "hsr_batch_bad_state", "hsr_batch_get_field",
     "hsr_batch_set_profiling", "hsr_batch_last_timing", "hsr_batch_set_graph", "hsr_batch_set_persistent", "hsr_batch_is_persistent",
-    "hsr_batch_obs_openai", "hsr_batch_obs_openai_dev", "hsr_batch_set_debug", "hsr_batch_cap_counts", "hsr_batch_cap_histogram", "hsr_batch_newton_trips", "hsr_batch_set_schedule", "hsr_batch_set_solo", "hsr_batch_solo_handovers", "hsr_batch_set_goals",
+    "hsr_batch_obs_openai", "hsr_batch_obs_openai_dev", "hsr_batch_set_debug", "hsr_batch_cap_counts", "hsr_batch_cap_histogram", "hsr_batch_newton_trips", "hsr_batch_packing", "hsr_batch_set_schedule", "hsr_batch_set_solo", "hsr_batch_solo_handovers", "hsr_batch_set_goals",
     "hsr_batch_phase_cycles", "hsr_batch_block_times", "hsr_batch_kernel_times", "hsr_batch_set_queue", "hsr_batch_set_mpr_warm",
 ]
 
@@ -99,6 +99,7 @@ def load_library():
     L.hsr_batch_cap_counts.argtypes = [vp, C.POINTER(C.c_ulonglong)]
     L.hsr_batch_cap_histogram.argtypes = [vp, C.POINTER(C.c_ulonglong)]
     L.hsr_batch_newton_trips.argtypes = [vp, C.POINTER(C.c_int32)]
+    L.hsr_batch_packing.argtypes = [vp, C.POINTER(C.c_int32)]
     L.hsr_batch_set_solo.argtypes = [vp, C.c_int, C.c_float]
     L.hsr_batch_solo_handovers.argtypes = [vp, C.POINTER(C.c_int)]
     _lib = L
@@ -331,6 +332,13 @@ class BatchSim:
         out = np.empty(self.n, np.int32)
         _check(self._L, self._L.hsr_batch_newton_trips(self._b, out.ctypes.data_as(C.POINTER(C.c_int32))))
         return out
+
+    def packing(self, envs_per_wave: int):
+        """env held by every lane group of every task of the last persistent launch (-1: empty), [tasks, envs_per_wave]."""
+        slots = (self.n + envs_per_wave - 1) // envs_per_wave * envs_per_wave
+        out = np.empty(slots, np.int32)
+        _check(self._L, self._L.hsr_batch_packing(self._b, out.ctypes.data_as(C.POINTER(C.c_int32))))
+        return out.reshape(-1, envs_per_wave)
 
     def last_timing(self):
         tot = C.c_float(0); k = (C.c_float * 3)(); n = (C.c_int * 3)()

@@ -172,6 +172,11 @@ int hsr_batch_cap_histogram(hsr_batch *b, unsigned long long *out /*[8]*/);
 /* Newton iterations every env ran over the last (up to) 100 substeps of its previous env-step launch: the hardness measure
  * hsr_batch_set_schedule packs by (the solver's iteration count MuJoCo reports as mjData.solver_iter, summed). */
 int hsr_batch_newton_trips(hsr_batch *b, int32_t *out /*[n_envs]*/);
+/* the packing the last persistent launch ran with (k_schedule, hsrsim.hip): out[slot] = env that lane group `slot % (64 / lanes per env)` of task
+ * `slot / (64 / lanes per env)` held, -1 = empty; ceil(n_envs / envs per wave) * envs per wave entries.  Contract (tests/test_gpu_hotpath.py): every env exactly
+ * once; per chunk of 8192 envs the first lane group of task w holds the env with the w-th most iterations (ties: lower index), the other groups are
+ * filled from the easy end.  Results never depend on it. */
+int hsr_batch_packing(hsr_batch *b, int32_t *out /*[ceil(n_envs / epw) * epw]*/);
 
 /* diagnostics (meaningful only in the -DHSR_PHASE_TIMING build, libhsrsim_timing.so; tools/phase_timing.py,
  * tools/block_times.py): per-phase cycle sums of the last launches, and per-workgroup

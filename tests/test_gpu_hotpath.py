@@ -984,6 +984,51 @@ def test_full_size_invariants(models, cfg, n):
     assert len(errs) >= 1 and np.median(errs) < 1e-4, errs
 
 
+@pytest.mark.parametrize("cfg,n", [("cfg3", 8192), ("cfg2", 9001), ("cfg4", 300)])
+def test_packing_of_a_launch_follows_its_contract(models, cfg, n):
+    """k_schedule (hsrsim.hip): per chunk of 8192 envs the envs are ordered by the Newton iterations of their previous env-step (more first, ties:
+    lower index first); the first lane group of task w holds the w-th of that order, the other lane groups are filled from the easy end; every env
+    is held exactly once.  Checked against a numpy restatement on the iteration counts the first env-step left behind - a full chunk (every stage of
+    the sorting network: in registers, across the lanes of a wave, across waves), two chunks with a ragged second one, and a 32-lane model."""
+    import sys
+    from pathlib import Path
+    sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+    from bench import sample_inputs, GEOFENCE
+    m = models[cfg]
+    q0, goal = sample_inputs(m, n, 0, 0)
+    bid = m.body_id(m.block_body()) if m.block_body() else -1
+    rng = np.random.Generator(np.random.Philox(key=[5, 0]))
+    lo, hi = m.act_ctrlrange[:, 0].astype(np.float32), m.act_ctrlrange[:, 1].astype(np.float32)
+    sim = hs.BatchSim(m, n)
+    assert sim.is_persistent()
+    sim.reset(qpos0=q0, mocap=goal)
+    for _ in range(3):              # from the reset state nothing touches anything: every env would report one iteration per substep
+        sim.step(rng.uniform(lo, hi, (n, m.nu)).astype(np.float32), 300, bid, GEOFENCE)
+    trips = sim.newton_trips().astype(np.int64)
+    assert trips.max() > trips.min()                       # something to sort by
+    sim.step(rng.uniform(lo, hi, (n, m.nu)).astype(np.float32), 3, bid, GEOFENCE)
+    epw = 4 if m.nv <= 16 else 2
+    got = sim.packing(epw)
+    sim.close()
+    want = np.full_like(got, -1)
+    for e0 in range(0, n, 8192):
+        nc = min(8192, n - e0)
+        order = e0 + np.lexsort((np.arange(nc), -np.minimum(trips[e0:e0 + nc], 0x1fffe)))        # iterations descending, then index ascending
+        nw = (nc + epw - 1) // epw
+        for j in range(epw):
+            w = np.arange(nw)
+            if j == 0:
+                idx = w
+            else:
+                r = (j - 1) * nw + w
+                idx = np.where(r < nc - nw, nc - 1 - r, -1)
+            ok = (idx >= 0) & (idx < nc)
+            want[e0 // epw + w[ok], j] = order[idx[ok]]
+    held = np.sort(got[got >= 0])
+    assert np.array_equal(held, np.arange(n)), "an env is held twice or not at all"
+    assert np.array_equal(got, want), f"{(got != want).sum()} slots differ from the contract"
+
+
 @pytest.mark.parametrize("cfg", ["cfg2", "cfg3", "cupboard"])
 def test_solo_servers_follow_the_plain_run(models, cfg):
     """Round 4: hard envs leave their task at the end of a round of the work queue and a solo server runs them alone in a wave to the end
