@@ -158,6 +158,8 @@ def main():
     ap.add_argument("--config", default="cfg3")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-gather-overlap", action="store_true", help="N > 1: issue the all-gather of an env-step on the batch stream (every rank then waits for the "
+                    "slowest rank of every env-step) instead of on a side stream overlapped with the next env-step")
     ap.add_argument("--no-persistent", action="store_true", help="per-substep kernels instead of the persistent env-step kernel")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="control-flow rehearsal of the N>1 path on a box with one GPU: every rank uses cuda:0 and the all-gather "
@@ -232,7 +234,9 @@ def main():
     # torch ops (packing, the RCCL all-gather) are enqueued on the batch's own stream
     ext = torch.cuda.ExternalStream(sim.stream_ptr(), device=dev)
     torch.cuda.set_stream(ext)
-    gather = hdist.StepGather(n, nobs, world, dev) if world > 1 else None
+    # the collective of env-step k overlaps env-step k + 1 (RCCL; the gloo rehearsal goes through host copies and stays in line)
+    gather_overlap = world > 1 and not args.rehearse_on_one_gpu and not args.no_gather_overlap
+    gather = hdist.StepGather(n, nobs, world, dev, overlap=gather_overlap) if world > 1 else None
 
     last_gathered = [None]
 
@@ -355,7 +359,7 @@ def main():
                                f"steps_per_action={STEPS_PER_ACTION}, geofence={GEOFENCE}, ctrl~U(ctrlrange) per env-step, done envs reset",
                    "envs_per_gpu": n, "global_envs": world * n, "substeps_per_env_step": STEPS_PER_ACTION,
                    "mean_substeps_executed": mean_substeps, "done_fraction": dones / (n * K),
-                   "parallelism": f"env-shard x{world}" + (f" + all-gather(obs,reward,done) over {'gloo (rehearsal)' if args.rehearse_on_one_gpu else 'RCCL'}, {dist.get_world_size()} ranks" if world > 1 else ""),
+                   "parallelism": f"env-shard x{world}" + (f" + all-gather(obs,reward,done) over {'gloo (rehearsal)' if args.rehearse_on_one_gpu else 'RCCL'}, {dist.get_world_size()} ranks{', overlapped with the next env-step' if gather_overlap else ''}" if world > 1 else ""),
                    "cap_hits": {"contacts_beyond_nconmax": cap_con / max(cap_total, 1), "rows_beyond_njmax": cap_row / max(cap_total, 1),
                                 "items_beyond_64_per_env": cap_item / max(cap_total, 1), "env_substeps": cap_total,
                                 "nconmax_njmax": [int(m.arrays["sizes"][10]), int(m.arrays["sizes"][11])], "note": "fraction of (env, substep) pairs; MuJoCo's own caps are 100 / 500 (world.xml:44)"},

@@ -67,32 +67,71 @@ def all_gather_step(packed_local, world: int, out=None, equal_shards=None):
 
 class StepGather:
     """The per-env-step exchange of the sharded run: pack obs / reward / done of the local shard into one fp32
-    buffer [N_local, nq+nv+2] and all-gather it into [world * N_local, nq+nv+2], on torch's CURRENT stream - bench.py makes that the
-    batch's own HIP stream (torch.cuda.ExternalStream), so the collective is ordered after the env-step kernel without a host sync.
+    buffer [N_local, nq+nv+2] and all-gather it into [world * N_local, nq+nv+2].  The packing runs on torch's CURRENT stream - bench.py
+    makes that the batch's own HIP stream (torch.cuda.ExternalStream), so it is ordered after the env-step kernel without a host sync.
     Equal shards only (the weak-scaling layout); the buffers are allocated once.  With `always=True` the collective is issued even
-    for a single rank (RCCL accepts a one-rank communicator): the GPU test uses that to execute this exact code path on one GPU."""
+    for a single rank (RCCL accepts a one-rank communicator): the GPU test uses that to execute this exact code path on one GPU.
 
-    def __init__(self, n_local: int, nobs: int, world: int, device, always: bool = False):
+    overlap=False: the collective is issued on the current stream too - the next env-step of this rank starts when every rank has delivered
+    this one (a rank-wide barrier per env-step: the sharded run then advances at the pace of the slowest rank of EVERY step).
+    overlap=True (RCCL only): the collective runs on a side stream, behind an event recorded after the packing, into one of two buffer pairs;
+    the current stream goes on with the next env-step and only waits - two steps later, before it packs into the same pair again - for the
+    collective that read it.  Ranks drift by up to two env-steps instead of meeting at every one; the gathered buffer of a step is valid
+    once `wait(result)` has been called (a stream wait, no host sync) or the device has been synchronised."""
+
+    def __init__(self, n_local: int, nobs: int, world: int, device, always: bool = False, overlap: bool = False):
         import torch
         self.world, self.nobs, self.always = world, nobs, always
-        self.pack = torch.empty((n_local, nobs + 2), dtype=torch.float32, device=device)
-        self.all = torch.empty((world * n_local, nobs + 2), dtype=torch.float32, device=device) if (world > 1 or always) else self.pack
+        exchange = world > 1 or always
+        self.overlap = bool(overlap and exchange)
+        nbuf = 2 if self.overlap else 1
+        self.packs = [torch.empty((n_local, nobs + 2), dtype=torch.float32, device=device) for _ in range(nbuf)]
+        self.alls = [torch.empty((world * n_local, nobs + 2), dtype=torch.float32, device=device) if exchange else self.packs[i] for i in range(nbuf)]
+        self.pack, self.all = self.packs[0], self.alls[0]
+        self.side = torch.cuda.Stream(device=device) if self.overlap else None
+        self.done_ev = [None] * nbuf          # fired when the collective that used buffer pair i has finished
+        self.k = 0
+
+    def wait(self, gathered=None):
+        """Make the current stream wait for the collective that fills `gathered` (default: every collective issued so far)."""
+        if not self.overlap:
+            return
+        import torch
+        cur = torch.cuda.current_stream()
+        for i, ev in enumerate(self.done_ev):
+            if ev is not None and (gathered is None or gathered.data_ptr() == self.alls[i].data_ptr()):
+                cur.wait_event(ev)
 
     def __call__(self, obs, reward, done):
+        import torch
         import torch.distributed as dist
         nobs = self.nobs
-        self.pack[:, :nobs] = obs
-        self.pack[:, nobs] = reward
-        self.pack[:, nobs + 1] = done
+        i = self.k % len(self.packs)
+        self.k += 1
+        if self.overlap and self.done_ev[i] is not None:
+            torch.cuda.current_stream().wait_event(self.done_ev[i])          # the collective of two steps ago has read pack[i] / written all[i]
+        pack, out = self.packs[i], self.alls[i]
+        pack[:, :nobs] = obs
+        pack[:, nobs] = reward
+        pack[:, nobs + 1] = done
         if (self.world > 1 or self.always) and dist.is_initialized():
             if dist.get_backend() == "gloo":
-                host = self.pack.cpu()
+                host = pack.cpu()
                 bufs = [host.new_empty(host.shape) for _ in range(self.world)]
                 dist.all_gather(bufs, host)
-                self.all.copy_(__import__("torch").cat(bufs, dim=0))
+                out.copy_(torch.cat(bufs, dim=0))
+            elif self.overlap:
+                packed = torch.cuda.Event()
+                packed.record(torch.cuda.current_stream())
+                with torch.cuda.stream(self.side):
+                    self.side.wait_event(packed)
+                    dist.all_gather_into_tensor(out, pack)                   # torch runs it on its RCCL stream, ordered behind and before `side`
+                    ev = torch.cuda.Event()
+                    ev.record(self.side)
+                self.done_ev[i] = ev
             else:
-                dist.all_gather_into_tensor(self.all, self.pack)
-        return self.all
+                dist.all_gather_into_tensor(out, pack)
+        return out
 
 
 def init_process_group(backend: str, device=None):

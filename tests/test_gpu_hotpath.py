@@ -526,11 +526,14 @@ def test_several_goals_all_in_range(models):
         env.close()
 
 
-def test_rccl_all_gather_on_the_batch_stream_one_rank(models, monkeypatch):
+@pytest.mark.parametrize("overlap", [False, True])
+def test_rccl_all_gather_on_the_batch_stream_one_rank(models, monkeypatch, overlap):
     """The exchange step of the sharded run (hsr_env_amd.dist.StepGather: pack + all_gather_into_tensor, backend "nccl" = RCCL, the
     process group bound to the device, issued on the batch's own HIP stream through torch.cuda.ExternalStream) executed on the one
     GPU there is: a one-rank communicator, so that the first multi-GPU run is not the first execution of this code.  The gathered
-    buffer must equal obs | reward | done of the step, with no host synchronisation between the env-step and the collective."""
+    buffer must equal obs | reward | done of the step, with no host synchronisation between the env-step and the collective.
+    overlap=True: the collective on StepGather's side stream behind an event, two buffer pairs - the mode bench.py uses for N > 1; the
+    buffers of the last TWO env-steps must hold those steps' outputs (the batch stream ran ahead of the collectives)."""
     import os
     import socket
     import torch
@@ -562,13 +565,20 @@ def test_rccl_all_gather_on_the_batch_stream_one_rank(models, monkeypatch):
         torch.cuda.synchronize()
         ext = torch.cuda.ExternalStream(sim.stream_ptr(), device=dev)
         with torch.cuda.stream(ext):
-            gather = hd.StepGather(n, nobs, 1, dev, always=True)
-            for _ in range(3):
+            gather = hd.StepGather(n, nobs, 1, dev, always=True, overlap=overlap)
+            assert gather.overlap == overlap
+            outs, kept = [], []
+            for _ in range(4):
                 sim.step_dev(d_ctrl.data_ptr(), 25, m.body_id("block0"), 0.5, d_obs.data_ptr(), d_rew.data_ptr(), d_done.data_ptr(), d_ns.data_ptr())
                 out = gather(d_obs, d_rew, d_done)
+                outs.append(out); kept.append(d_obs.clone())
+            gather.wait(out)
         sim.sync()
         torch.cuda.synchronize()
-        assert out.data_ptr() != gather.pack.data_ptr() and out.shape == (n, nobs + 2)
+        assert out.data_ptr() not in [p_.data_ptr() for p_ in gather.packs] and out.shape == (n, nobs + 2)
+        if overlap:      # two buffer pairs: the last two steps are both still there
+            assert outs[-1].data_ptr() != outs[-2].data_ptr() and outs[-1].data_ptr() == outs[-3].data_ptr()
+            assert torch.equal(hd.unpack_step(outs[-2])[0], kept[-2]) and not torch.equal(kept[-2], kept[-1])
         o, r, d = hd.unpack_step(out)
         assert torch.equal(o, d_obs) and torch.equal(r, d_rew) and torch.equal(d, d_done > 0)
         t, qq, vv = sim.get_state()
