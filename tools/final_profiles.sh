@@ -5,6 +5,7 @@ TAG=${1:-r04}
 mkdir -p gpurun_out/r4
 export TMPDIR=/tmp
 bash tools/profile_round.sh $TAG > gpurun_out/r4/final_profile_round.log 2>&1 || { echo "profile_round failed"; tail -5 gpurun_out/r4/final_profile_round.log; exit 1; }
+bash tools/pmc_mix.sh $TAG > gpurun_out/r4/final_pmc_mix.log 2>&1 || { echo "pmc_mix failed"; exit 1; }
 for c in cfg1 cfg2 cfg3 cfg4 cupboard; do HSR_CFG=$c HSR_LIB=$PWD/hsr_env_amd/libhsrsim_life.so python tools/block_life.py --json > gpurun_out/r4/final_life_$c.log 2>&1 || exit 1; done
 HSR_LIB=$PWD/hsr_env_amd/libhsrsim_timing.so python tools/block_times.py > gpurun_out/r4/final_bt.log 2>&1 || exit 1
 HSR_CFG=cfg4 HSR_LIB=$PWD/hsr_env_amd/libhsrsim_timing.so python tools/block_times.py > gpurun_out/r4/final_bt4.log 2>&1 || exit 1

@@ -47,6 +47,16 @@ for k, v in sq.items():
         summary["_sq_per_wave_per_substep"] = {c: round(x / n, 1) for c, x in sorted(v.items())}
         summary["_sq_per_wave_per_substep"]["note"] = (f"{tag}: SQ counters of k_env_step_mf divided by (launches x {waves} waves x {nsub} substeps); "
                                                        "*_CYCLES / ACTIVE / WAIT in units of 4 clocks")
+mix = {}
+for d in ("pmc_mixa", "pmc_mixb"):          # tools/pmc_mix.sh: instruction mix and issue cycles per class
+    cm, _ = counters(d)
+    for k, v in cm.items():
+        if "k_env_step_mf" in k:
+            mix.update({c: round(x / (waves * nsub), 1) for c, x in v.items()})
+if mix:
+    mix["note"] = (f"{tag}: per wave and substep, last launch of k_env_step_mf (tools/pmc_mix.sh); SQ_ACTIVE_INST_* / SQ_INST_CYCLES_* / SQ_WAVE_CYCLES / SQ_WAIT_* in units of 4 clocks: "
+                   "the share of a wave's lifetime spent issuing each instruction class - the rest is waiting (s_waitcnt, issue arbitration)")
+    summary["_mix_per_wave_per_substep"] = dict(sorted(mix.items()))
 wr, nwr = counters("pmc_wr")
 for k, v in wr.items():
     if "k_env_step_mf" in k and v.get("TCC_EA0_WRREQ_sum"):
