@@ -744,6 +744,10 @@ static int batch_init(hsr_batch *b, const hsr_model *m, int n_envs) {
         }
         // what the persistent kernel's lane maps and kinematics assume (kin2.h, persist.h); a model outside it runs the per-substep chain
         bool ok = d.nq <= b->group && d.nv <= b->group && d.nlink <= b->group && d.nlink <= NLMAX && d.ngeom <= 64 && d.npair < (1 << 14) && d.maxdepth <= 9;
+        {   // the persistent kernel keeps every dof's chain to the root in one 64-bit register, 6 bits per dof (persist.h: anc_c)
+            const int *dp = m->i32("dof_parent");
+            for (int c = 0; ok && c < d.nv; c++) { int depth = 0; for (int k = c; k >= 0 && depth <= 10; k = dp[k]) depth++; if (depth > 10) ok = false; }
+        }
         {
             const int *dn = m->i32("link_dofnum"), *lf = m->i32("link_free"), *lp = m->i32("link_parent"), *gl = m->i32("geom_link");
             for (int l = 1; l < d.nlink; l++) {

@@ -206,9 +206,16 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
     int my_type = -1, my_qadr = 0, my_quat_lane = -1, my_limited = 0, my_act = -1;
     float lim_lo = 0, lim_hi = 0, lim_sr0 = 1, lim_sr1 = 1, lim_iw = 0, lim_si[5] = {0, 0, 0, 0, 0}, lim_B = 0, lim_K = 0;
     float act_p[6] = {0, 0, 0, 0, 0, 0};
+    // the dof tree as this lane sees it, in two registers (SOLVE_LANE_TABLES, solve_body.inc): bit l of sub_c = link l moves with dof c; anc_c = the
+    // dofs from c up to the root, 6 bits each (dof + 1, 0 ends the list) - so that the inertia rows walk registers, not a chain of LDS reads
+    unsigned sub_c = 0;
+    unsigned long long anc_c = 0;
     {
         PERSIST_LANE_VIEW(tid0)
         if (isdof) {
+            for (int l = 1; l < m.nlink && l < 32; l++) sub_c |= ((unsigned)(m.link_dofmask[l] >> c) & 1u) << l;
+            int sh = 0;
+            for (int k = c; k >= 0 && sh < 60; k = m.dof_parent[k], sh += 6) anc_c |= (unsigned long long)(k + 1) << sh;
             my_type = m.dof_type[c]; my_qadr = m.dof_qposadr[c]; my_limited = m.dof_limited[c]; my_act = m.dof_act[c];
             my_quat_lane = m.link_dofadr[m.dof_link[c]] + 3;
             damp_c = m.dof_damping[c];
@@ -644,7 +651,11 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
 #define SOLVE_STORE_DIAG dbg_store
 #define SOLVE_COUNT_CAPS 1
 #define PAIR_CNT8(p) (*reinterpret_cast<const unsigned long long *>(pcnt + (p)))
+#ifndef HSR_NO_LANE_TABLES
+#define SOLVE_LANE_TABLES 1
+#endif
 #include "solve_body.inc"
+#undef SOLVE_LANE_TABLES
 #undef PAIR_CNT8
 #undef SOLVE_COUNT_CAPS
 #undef SOLVE_STORE_DIAG
