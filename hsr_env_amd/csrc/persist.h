@@ -204,7 +204,6 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
     // per-lane model constants of the solver: loaded once per launch (the registers are there since the exact-nv build)
     float my_ctrl = 0, damp_c = 0;
     int my_type = -1, my_qadr = 0, my_quat_lane = -1, my_limited = 0, my_act = -1;
-    float lim_lo = 0, lim_hi = 0, lim_sr0 = 1, lim_sr1 = 1, lim_iw = 0, lim_si[5] = {0, 0, 0, 0, 0}, lim_B = 0, lim_K = 0;
     float act_p[6] = {0, 0, 0, 0, 0, 0};
     // the dof tree as this lane sees it, in two registers (SOLVE_LANE_TABLES, solve_body.inc): bit l of sub_c = link l moves with dof c; anc_c = the
     // dofs from c up to the root, 6 bits each (dof + 1, 0 ends the list) - so that the inertia rows walk registers, not a chain of LDS reads
@@ -219,11 +218,6 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
             my_type = m.dof_type[c]; my_qadr = m.dof_qposadr[c]; my_limited = m.dof_limited[c]; my_act = m.dof_act[c];
             my_quat_lane = m.link_dofadr[m.dof_link[c]] + 3;
             damp_c = m.dof_damping[c];
-            lim_lo = m.dof_range[2 * c]; lim_hi = m.dof_range[2 * c + 1]; lim_sr0 = m.dof_solref[2 * c]; lim_sr1 = m.dof_solref[2 * c + 1];
-            lim_iw = m.dof_invweight0[c];
-#pragma unroll
-            for (int j = 0; j < 5; j++) lim_si[j] = m.dof_solimp[5 * c + j];
-        { const float dmax = fminf(fmaxf(lim_si[1], HSR_MINIMP), HSR_MAXIMP); lim_B = 2.0f / (dmax * lim_sr0); lim_K = 1.0f / (dmax * dmax * lim_sr0 * lim_sr0 * lim_sr1 * lim_sr1); }
             if (my_act >= 0) {
                 act_p[0] = m.act_kp[my_act]; act_p[1] = m.act_gear[my_act];
                 act_p[2] = m.act_ctrlrange[2 * my_act]; act_p[3] = m.act_ctrlrange[2 * my_act + 1];
@@ -654,8 +648,10 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
 #ifndef HSR_NO_LANE_TABLES
 #define SOLVE_LANE_TABLES 1
 #endif
+#define SOLVE_LIMITS_FROM_MODEL 1
 #include "solve_body.inc"
 #undef SOLVE_LANE_TABLES
+#undef SOLVE_LIMITS_FROM_MODEL
 #undef PAIR_CNT8
 #undef SOLVE_COUNT_CAPS
 #undef SOLVE_STORE_DIAG
