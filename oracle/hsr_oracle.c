@@ -89,6 +89,10 @@ typedef struct {
     double *qacc, *qfrc_constraint;
     int solver_niter, bad;
     double solver_cost;
+    /* introspection for tests/test_oracle_optimality.py: accepted cost after the warm-start choice ([0]) and after every Newton iteration, the largest
+     * number of line-search evaluations one iteration needed, and whether a step that would have raised the cost was refused */
+    double solver_trace[104];
+    int solver_ntrace, solver_ls_max, solver_refused;
     int euler_rhs_macc;   /* test option (ho_set_euler_rhs): mj_Euler's damped solve takes M qacc as its right-hand side, as the HIP path does */
 } ho_data;
 
@@ -1019,6 +1023,8 @@ static void ho_solve(const ho_model *m, ho_data *d) {
     if (cost_w < cost_s) { memcpy(qacc, d->qacc_warmstart, sizeof(double)*(size_t)nv); EVAL_AT(qacc, cost); }
     else { memcpy(qacc, d->qacc_smooth, sizeof(double)*(size_t)nv); cost = cost_s; }
     int iter = 0;
+    d->solver_ntrace = 0; d->solver_ls_max = 0; d->solver_refused = 0;
+    d->solver_trace[d->solver_ntrace++] = cost;
     for (; iter < maxit; iter++) {
         /* gradient and Hessian */
         for (int i = 0; i < nv; i++) {
@@ -1063,6 +1069,7 @@ static void ho_solve(const ho_model *m, ho_data *d) {
          * line search carries the same rule). */
         for (int it = 0; it < ls_maxit; it++) {
             ls_eval(d, jar, jv, alpha, g1, g2, &dp, &hp);
+            if (it + 1 > d->solver_ls_max) d->solver_ls_max = it + 1;
             if (fabs(dp) < gtol) break;
             if (dp < 0) lo = alpha; else hi = alpha;
             double nxt = alpha - dp / hp;
@@ -1077,8 +1084,10 @@ static void ho_solve(const ho_model *m, ho_data *d) {
         if (cost > oldcost) {          /* a step that raises the cost is never taken (MuJoCo's search returns a point no worse than alpha = 0) */
             for (int i = 0; i < nv; i++) qacc[i] -= alpha*search[i];
             EVAL_AT(qacc, cost);
+            d->solver_refused = 1;
             break;
         }
+        if (d->solver_ntrace < 104) d->solver_trace[d->solver_ntrace++] = cost;
         if (scale*(oldcost - cost) < tol) { iter++; break; }
     }
     d->solver_niter = iter; d->solver_cost = cost;
@@ -1201,6 +1210,15 @@ int ho_nefc(const ho_data *d) { return d->nefc; }
 int ho_bad(const ho_data *d) { return d->bad; }
 int ho_solver_niter(const ho_data *d) { return d->solver_niter; }
 void ho_set_euler_rhs(ho_data *d, int m_qacc) { d->euler_rhs_macc = m_qacc != 0; }
+/* solver introspection (tests only): which = 0 number of trace entries, 1 largest line-search evaluation count of an iteration, 2 a cost-raising step was refused,
+ * 3 number of active limit rows (they precede the contact rows) */
+int ho_solver_stat(const ho_data *d, int which) { return which == 0 ? d->solver_ntrace : which == 1 ? d->solver_ls_max : which == 2 ? d->solver_refused : d->nlimit_active; }
+double *ho_solver_trace(ho_data *d) { return d->solver_trace; }
+/* contact i -> out[0:5] friction, [5] first constraint row */
+void ho_contact_get2(const ho_data *d, int i, double *out) {
+    const ho_contact *c = d->contact + i;
+    memcpy(out, c->friction, 5*sizeof(double)); out[5] = c->efc_address;
+}
 /* contact i -> out[0:3] pos, [3:12] frame, [12] dist, [13] geom1, [14] geom2, [15] dim, [16] mu */
 void ho_contact_get(const ho_data *d, int i, double *out) {
     const ho_contact *c = d->contact + i;

@@ -46,6 +46,9 @@ def lib():
         for f in ("ncon", "nefc", "bad", "solver_niter"):
             getattr(L, "ho_" + f).restype = C.c_int; getattr(L, "ho_" + f).argtypes = [vp]
         L.ho_contact_get.argtypes = [vp, C.c_int, dp]
+        L.ho_contact_get2.argtypes = [vp, C.c_int, dp]
+        L.ho_solver_stat.restype = C.c_int; L.ho_solver_stat.argtypes = [vp, C.c_int]
+        L.ho_solver_trace.restype = dp; L.ho_solver_trace.argtypes = [vp]
         L.ho_set_euler_rhs.argtypes = [vp, C.c_int]; L.ho_set_euler_rhs.restype = None
         L.ho_batch_env_step.restype = C.c_int
         L.ho_batch_env_step.argtypes = [vp, C.c_int, dp, dp, dp, dp, dp, C.c_int, C.c_int, C.c_double, ip, C.c_int]
@@ -117,6 +120,22 @@ class OracleSim:
         for i in range(self.ncon):
             self._L.ho_contact_get(self._d, i, _dp(out[i]))
         return out
+
+    def contact_cones(self):
+        """Per contact: (first constraint row, dim, mu, friction[5]) - what a cost function needs besides efc()."""
+        out = []
+        a, b = np.zeros(17), np.zeros(6)
+        for i in range(self.ncon):
+            self._L.ho_contact_get(self._d, i, _dp(a)); self._L.ho_contact_get2(self._d, i, _dp(b))
+            out.append((int(b[5]), int(a[15]), float(a[16]), b[:5].copy()))
+        return out
+
+    def solver_stats(self):
+        """(accepted costs: after the warm-start choice, then after every Newton iteration; largest line-search evaluation count of an
+        iteration; a cost-raising step was refused; number of active limit rows)."""
+        n = self._L.ho_solver_stat(self._d, 0)
+        tr = np.ctypeslib.as_array(self._L.ho_solver_trace(self._d), shape=(104,))[:n].copy()
+        return tr, self._L.ho_solver_stat(self._d, 1), bool(self._L.ho_solver_stat(self._d, 2)), self._L.ho_solver_stat(self._d, 3)
 
     def efc(self):
         ne, nv = self.nefc, self.model.nv

@@ -43,6 +43,10 @@ nsup = a[:, 5] & 0xffffff; ncall = (a[:, 5] >> 24) & 0xffffff; nmax = a[:, 5] >>
 print('MPR runs / substep: mean %.2f, slowest 10 %s; supports per run: mean %.1f, slowest 10 %s; max supports in a run %d' % (
     ncall.mean() / 300, (ncall[o[-10:]] / 300).round(2), nsup.sum() / max(ncall.sum(), 1), (nsup[o[-10:]] / np.maximum(ncall[o[-10:]], 1)).round(1), nmax.max()))
 print('narrowphase items / substep: mean %.2f, slowest 10 %s' % (a[:, 6].mean() / 300, (a[o[-10:], 6] / 300).round(2)))
+if os.environ.get('HSR_LSCOUNT'):      # timing build with -DHSR_LSCOUNT: counter 3 = line-search evaluations | own Newton iterations << 32 of lane 0's env
+    ev = a[:, 7] & 0xffffffff; itn = a[:, 7] >> 32
+    print('line-search evaluations per Newton iteration (lane 0 env): all %.2f, slowest 20 %.2f (its iterations / substep %.2f), median 20 %.2f' % (
+        ev.sum() / max(itn.sum(), 1), ev[o[-20:]].sum() / max(itn[o[-20:]].sum(), 1), itn[o[-20:]].mean() / 300, ev[o[nb // 2 - 10: nb // 2 + 10]].sum() / max(itn[o[nb // 2 - 10: nb // 2 + 10]].sum(), 1)))
 print('nefc sum / substep: mean %.2f, slowest 10 %s' % (a[:, 7].mean() / 300, (a[o[-10:], 7] / 300).round(2)))
 print('corr(life, newton) %.3f  corr(life, items) %.3f corr(life, nefc) %.3f' % (np.corrcoef(life, a[:, 4])[0, 1], np.corrcoef(life, a[:, 6])[0, 1], np.corrcoef(life, a[:, 7])[0, 1]))
 A = np.stack([np.ones(nb), a[:, 4], a[:, 6], a[:, 7]], 1).astype(np.float64)
