@@ -93,11 +93,52 @@ def cpu_baseline(m, q0, goal, ctrl, cores):
     t1 = run(min(N, 16), 1, threads=1) / min(N, 16)                       # calibrate one thread, then about 5 s on it
     n1 = int(max(1, min(N, 5.0 / max(t1, 1e-9))))
     dt1 = run(n1, 1, threads=1)
-    return dict(value=n * reps / dt, unit="env-steps/s", cores=cores, kind="port",
+    eff = (n * reps / dt) / (cores * (n1 / dt1))
+    extra = {}
+    if eff < 0.5:
+        extra["note"] = (f"the {cores} threads deliver {eff * cores:.1f}x one thread: this process does not get {cores} cores' worth of CPU on this box "
+                         "(shared or throttled host); the single-core figure is the reliable one")
+    return dict(value=n * reps / dt, unit="env-steps/s", cores=cores, kind="port", parallel_efficiency=eff, **extra,
                 single_core={"value": n1 / dt1, "unit": "env-steps/s", "cores": 1, "sample": f"first {n1} envs x 1 env-step ({dt1:.1f} s)"},
                 sample=f"first {n} envs x {reps} env-steps x {STEPS_PER_ACTION} substeps of the same workload ({dt:.1f} s), "
                        f"oracle/hsr_oracle.c fp64 with OpenMP over envs ({cores} threads); stand-in for CPU mujoco-py, "
                        "which is not installable here")
+
+
+def capacity_leg(m, n, dev, device_id, K=3, W=2):
+    """SECONDARY figure, never the headline: the same env-step at `n` envs on this one GPU (tasks beyond the resident workgroups go through the work
+    queue), K timed env-steps after W warm-up ones - what the GPU delivers once the serial chain of the hardest env is amortised over more envs."""
+    import torch
+    from hsr_env_amd.sim import BatchSim
+    q0, goal = sample_inputs(m, n, 0, 0)
+    rng = np.random.Generator(np.random.Philox(key=[1, 0]))
+    lo, hi = m.act_ctrlrange[:, 0].astype(np.float32), m.act_ctrlrange[:, 1].astype(np.float32)
+    sim = BatchSim(m, n, device=device_id)
+    sim.reset(qpos0=q0, mocap=goal)
+    ext = torch.cuda.ExternalStream(sim.stream_ptr(), device=dev)
+    bid = m.body_id(m.block_body()) if m.block_body() else -1
+    with torch.cuda.stream(ext):
+        d_ctrl = [torch.from_numpy(rng.uniform(lo, hi, (n, m.nu)).astype(np.float32)).to(dev) for _ in range(K + W)]
+        rs = [sample_inputs(m, n, 2 + k, 0) for k in range(K + W)]
+        d_rq = [torch.from_numpy(r[0]).to(dev) for r in rs]; d_rg = [torch.from_numpy(r[1]).to(dev) for r in rs]
+        d_obs = torch.empty((n, m.nq + m.nv), dtype=torch.float32, device=dev); d_rew = torch.empty(n, dtype=torch.float32, device=dev)
+        d_done = torch.empty(n, dtype=torch.uint8, device=dev); d_ns = torch.empty(n, dtype=torch.int32, device=dev)
+
+        def env_step(k):
+            sim.step_dev(d_ctrl[k].data_ptr(), STEPS_PER_ACTION, bid, GEOFENCE, d_obs.data_ptr(), d_rew.data_ptr(), d_done.data_ptr(), d_ns.data_ptr())
+            sim.reset_dev(None, d_rq[k].data_ptr(), d_rg[k].data_ptr())
+        for k in range(W):
+            env_step(k)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(W, W + K):
+            env_step(k)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    bad, _ = sim.bad_state()
+    sim.close()
+    return {"envs_per_gpu": n, "value": n * K / dt, "unit": "env-steps/s", "ms_per_step": 1e3 * dt / K, "steps": K, "warmup": W, "bad_envs": int(bad.sum()),
+            "note": "secondary: throughput of ONE GPU at saturation (same workload, more envs per GPU, work queue); not the BASELINE configuration, never the headline"}
 
 
 def self_launch(args):
@@ -152,14 +193,18 @@ def self_launch(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--envs-per-gpu", type=int, default=8192)
     ap.add_argument("--config", default="cfg3")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--no-gather-overlap", action="store_true", help="N > 1: issue the all-gather of an env-step on the batch stream (every rank then waits for the "
-                    "slowest rank of every env-step) instead of on a side stream overlapped with the next env-step")
+    ap.add_argument("--gather-overlap", action="store_true", help="N > 1: issue the all-gather of env-step k on a side stream, overlapped with env-step k + 1 (ranks may drift "
+                    "by two env-steps; only legal when step k + 1 does not depend on the gathered obs of step k - an OPEN-loop number).  Default: the all-gather in "
+                    "line on the batch stream, every rank waits for it before its next env-step (closed loop: what a trainer that acts on the gathered obs needs)")
+    ap.add_argument("--no-gather-overlap", action="store_true", help=argparse.SUPPRESS)      # accepted for the command lines of round 4: in-line is the default now
+    ap.add_argument("--no-capacity", action="store_true", help="skip the secondary `capacity` leg (N = 1: a few env-steps at --capacity-envs envs on this GPU after the headline)")
+    ap.add_argument("--capacity-envs", type=int, default=65536)
     ap.add_argument("--no-persistent", action="store_true", help="per-substep kernels instead of the persistent env-step kernel")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="control-flow rehearsal of the N>1 path on a box with one GPU: every rank uses cuda:0 and the all-gather "
@@ -234,8 +279,9 @@ def main():
     # torch ops (packing, the RCCL all-gather) are enqueued on the batch's own stream
     ext = torch.cuda.ExternalStream(sim.stream_ptr(), device=dev)
     torch.cuda.set_stream(ext)
-    # the collective of env-step k overlaps env-step k + 1 (RCCL; the gloo rehearsal goes through host copies and stays in line)
-    gather_overlap = world > 1 and not args.rehearse_on_one_gpu and not args.no_gather_overlap
+    # closed loop by default: the collective of env-step k is in line on the batch stream; --gather-overlap moves it to a side stream under env-step k + 1
+    # (RCCL only; the gloo rehearsal goes through host copies and stays in line)
+    gather_overlap = world > 1 and not args.rehearse_on_one_gpu and args.gather_overlap
     gather = hdist.StepGather(n, nobs, world, dev, overlap=gather_overlap) if world > 1 else None
 
     last_gathered = [None]
@@ -309,7 +355,7 @@ def main():
     traffic = None
     traffic_source = None
     pmc = ROOT / "profiles" / "pmc_summary.json"
-    if pmc.exists():
+    if pmc.exists() and args.config == "cfg3" and n == 8192:          # the committed counter passes are of this workload only
         try:
             pj = json.loads(pmc.read_text())
             traffic = pj.get(names[dom].split("<")[0], {}).get("hbm_bytes_per_launch")
@@ -359,15 +405,16 @@ def main():
                                f"steps_per_action={STEPS_PER_ACTION}, geofence={GEOFENCE}, ctrl~U(ctrlrange) per env-step, done envs reset",
                    "envs_per_gpu": n, "global_envs": world * n, "substeps_per_env_step": STEPS_PER_ACTION,
                    "mean_substeps_executed": mean_substeps, "done_fraction": dones / (n * K),
+                   "gather_mode": (None if world == 1 else ("overlapped with the next env-step (open loop)" if gather_overlap else "in line (closed loop)")),
                    "parallelism": f"env-shard x{world}" + (f" + all-gather(obs,reward,done) over {'gloo (rehearsal)' if args.rehearse_on_one_gpu else 'RCCL'}, {dist.get_world_size()} ranks{', overlapped with the next env-step' if gather_overlap else ''}" if world > 1 else ""),
                    "cap_hits": {"contacts_beyond_nconmax": cap_con / max(cap_total, 1), "rows_beyond_njmax": cap_row / max(cap_total, 1),
                                 "items_beyond_64_per_env": cap_item / max(cap_total, 1), "env_substeps": cap_total,
                                 "nconmax_njmax": [int(m.arrays["sizes"][10]), int(m.arrays["sizes"][11])], "note": "fraction of (env, substep) pairs; MuJoCo's own caps are 100 / 500 (world.xml:44)"},
                    "substeps_per_s": value * mean_substeps, "persistent_kernel": persistent, "hipgraph": (not args.no_graph) and not persistent,
                    "bad_envs": int(bad.sum())},
-        "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+        "roofline": {"bound": "valu", "prescribed_bound": "hbm", "kernel": names[dom], "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
-                     "binding": "valu",        # the prescribed roofline is HBM (BASELINE); what binds is FP32 VALU issue / latency: see `valu` and `note`
+                     "binding": "valu",        # achieved / peak / frac / traffic are the prescribed HBM report (BASELINE); what binds is FP32 VALU issue / latency: see `valu` and `note`
                      "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_us": avg_us, **kernel_stats,
                      "workgroup_lifetimes": lifetimes,
                      "valu": valu,
@@ -375,6 +422,8 @@ def main():
                      "launches_per_env_step": {nm: k for nm, k in zip(names, k_n) if nm != "-"},
                      "note": "state stays L2/MALL-resident; the path is FP32-VALU/latency bound, not HBM bound (SURVEY.md 8d)"},
     }
+    if world == 1 and persistent and not args.no_capacity and args.capacity_envs > n:
+        out["capacity"] = capacity_leg(m, args.capacity_envs, dev, local_rank)
     if rank == 0 and not args.no_cpu_baseline:
         # rank 0 only, after the timed region (the other ranks wait at destroy_process_group): a line at N > 1 carries the baseline too
         out["cpu_baseline"] = cpu_baseline(m, q0, goal, ctrl_host, host_cores())

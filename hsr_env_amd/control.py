@@ -26,9 +26,10 @@ class ControlHSREnv(VecHSREnv):
         return t
 
 
-def main(env_args, n_envs=1, env_steps=0, random_actions=False):
-    env = ControlHSREnv(n_envs=n_envs, **env_args)
-    env.reset()
+def run(env, env_steps=0, random_actions=False):
+    """The reference's loop (hsr/control.py:66-76: `if done: env.reset()`, `done = env.control_agent()`) over all envs of the handle at once:
+    the envs that finished are reset by mask, the others go on.  env_steps <= 0 loops for ever like the reference.  Returns (env-steps, seconds)."""
+    n_envs = env.n_envs
     done = np.zeros(n_envs, dtype=bool)
     k, t0 = 0, time.perf_counter()
     while env_steps <= 0 or k < env_steps:
@@ -38,7 +39,16 @@ def main(env_args, n_envs=1, env_steps=0, random_actions=False):
         k += 1
     dt = time.perf_counter() - t0
     print(f"{k} env-steps x {n_envs} envs in {dt:.3f} s -> {k * n_envs / dt:.1f} env-steps/s")
-    env.close()
+    return k, dt
+
+
+def main(env_args, n_envs=1, env_steps=0, random_actions=False):
+    env = ControlHSREnv(n_envs=n_envs, **env_args)
+    env.reset()
+    try:
+        run(env, env_steps, random_actions)
+    finally:
+        env.close()
 
 
 if __name__ == '__main__':

@@ -1170,7 +1170,10 @@ extern "C" int hsr_batch_step_dev(hsr_batch *b, const float *d_ctrl, int n_subst
         if (!b->queue_chunk_set && b->slots > 0 && T >= 4 * b->slots) chunk = 50;
         while ((n_substeps + chunk - 1) / chunk > QUEUE_ROUNDS) chunk *= 2;
         // solo servers need the queue (a hard env leaves its task at the end of a round) and the env -> slot table
-        const bool solo = b->solo_ok && b->solo_servers > 0 && b->solo_servers <= 4096 && sched && b->slots > 0 && n_substeps >= 3 * chunk && (T + b->solo_servers <= b->slots || 4 * b->solo_servers <= b->slots);
+        // (a hand-over ticket packs env | substep << 20 into one int that must stay non-negative: fewer than 2048 substeps, at most 2^20 envs - beyond
+        // that the launch simply runs without servers)
+        const bool solo = b->solo_ok && b->solo_servers > 0 && b->solo_servers <= 4096 && sched && b->slots > 0 && n_substeps >= 3 * chunk && n_substeps < 2048 && b->N <= (1 << 20)
+                          && (T + b->solo_servers <= b->slots || 4 * b->solo_servers <= b->slots);
         const bool qon = b->slots > 0 && n_substeps >= 2 * chunk && (solo || b->queue == 1 || (b->queue < 0 && T > b->slots));
         int grid = T;
         dsl.solo_servers = 0;

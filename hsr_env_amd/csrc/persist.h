@@ -249,6 +249,7 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
     // skin when the list was built and has closed in by less since: no contact.  A pair on it runs its narrowphase every substep -
     // which reports a contact only where there is one - so the contact set is the one of culling every substep.
     int nitems = 0;                                        // wave-uniform
+    int trunc_mask = 0;                                    // wave-uniform: bit j = the list holds only the first 64 items of env j (counted in capstat[2] on every substep the list is used)
     bool list_ok = false;                                  // wave-uniform: sItems[0 .. nitems) is a valid list
     float acc_move = 0.f;                                  // this lane's env: bound on the move of any of its geoms since the list was built
     // ---------------- load the env state; it lives in registers for the whole run of substeps
@@ -458,10 +459,12 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
                 }
             }
             wave_sync();
+            trunc_mask = 0;
 #pragma unroll
-            for (int j = 0; j < EPB; j++) if (g == j && nit_env[j] > 64) cap_item += valid ? 1 : 0;      // more than 64 surviving pairs in ONE env: its contacts beyond them are dropped (a capacity event, counted in capstat[2]; NOT a diverged state)
+            for (int j = 0; j < EPB; j++) if (nit_env[j] > 64) trunc_mask |= 1 << j;      // more than 64 surviving pairs in ONE env: its contacts beyond them are dropped (a capacity event; NOT a diverged state)
             acc_move = 0.f; list_ok = true;
             }
+            if (trunc_mask && ((trunc_mask >> g) & 1) && valid) cap_item++;      // capstat[2]: (env, substep) pairs that ran on a truncated list - every substep the list is used, not only the one that built it
             PHASE(19);
             DBGCNT(2, nitems);
             wave_sync();

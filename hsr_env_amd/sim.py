@@ -298,8 +298,8 @@ class BatchSim:
         _check(self._L, self._L.hsr_batch_set_goals(self._b, n, a, b, d))
 
     def set_solo(self, servers: int, trips: float = 0.0) -> bool:
-        """Solo servers of the persistent kernel (include/hsrsim.h): `servers` workgroups run hard envs alone; 0 = off.  Never changes a
-        result.  False when the model's kernel instance has no server path."""
+        """Solo servers of the persistent kernel (include/hsrsim.h): `servers` workgroups run hard envs alone; 0 = off.  Results then
+        depend on the hand-over at rounding level (another summation order of the contact terms), not bit for bit.  False when the model's kernel instance has no server path."""
         rc = self._L.hsr_batch_set_solo(self._b, int(servers), float(trips))
         if rc < 0:
             _check(self._L, rc)
@@ -335,10 +335,13 @@ class BatchSim:
 
     def packing(self, envs_per_wave: int):
         """env held by every lane group of every task of the last persistent launch (-1: empty), [tasks, envs_per_wave]."""
-        slots = (self.n + envs_per_wave - 1) // envs_per_wave * envs_per_wave
-        out = np.empty(slots, np.int32)
+        if envs_per_wave not in (2, 4):
+            raise ValueError("envs_per_wave is 4 (16 lanes per env) or 2 (32 lanes per env)")
+        # the library writes ceil(N / epw) * epw entries with ITS envs-per-wave: the buffer covers either value whatever the caller passed
+        out = np.full(self.n + 64, -1, np.int32)
         _check(self._L, self._L.hsr_batch_packing(self._b, out.ctypes.data_as(C.POINTER(C.c_int32))))
-        return out.reshape(-1, envs_per_wave)
+        slots = (self.n + envs_per_wave - 1) // envs_per_wave * envs_per_wave
+        return out[:slots].reshape(-1, envs_per_wave)
 
     def last_timing(self):
         tot = C.c_float(0); k = (C.c_float * 3)(); n = (C.c_int * 3)()

@@ -137,8 +137,11 @@ int hsr_batch_set_debug(hsr_batch *b, int on);
  * of the launch take no tasks: they wait for envs that a worker has found hard - `trips` or more Newton iterations per substep over a
  * round of the work queue (0 keeps the current threshold) - and run each of them alone in a wave, from the substep its worker left it at to
  * the end of the env-step, while the task it came from goes on without it.  The launch ends with its slowest env's chain (hsr/env.py:118-131
- * is one serial loop per env); this shortens that chain.  0 servers = off.  A scheduling decision: an env's arithmetic does not depend
- * on who runs it (results bit-identical with it on or off).  Returns 1 (not an error) when the model's kernel instance has no server path. */
+ * is one serial loop per env); this shortens that chain.  0 servers = off.  A server's replicas sum the contact terms of the Hessian and
+ * of J^T f in another order than a worker does, and which envs get a server depends on timing: with servers on, results are reproducible to
+ * rounding (median |dobs| 1e-5 after an env-step, tests/test_gpu_hotpath.py::test_solo_servers_follow_the_plain_run), not bit for bit.  Launches of
+ * 2048 or more substeps or of more than 2^20 envs run without servers (the hand-over ticket is one int).  Returns 1 (not an error) when the
+ * model's kernel instance has no server path. */
 int hsr_batch_set_solo(hsr_batch *b, int servers, float trips);
 /* envs handed over to solo servers by the last persistent launch (synchronises) */
 int hsr_batch_solo_handovers(hsr_batch *b, int *out);

@@ -25,21 +25,27 @@ def _bench(args, timeout=900):
 
 
 @pytest.mark.gpu
-def test_two_ranks_on_one_gpu_reproduce_the_single_process_shards(tmp_path):
+@pytest.mark.parametrize("cfg", ["cfg3", "cfg4"])
+def test_two_ranks_on_one_gpu_reproduce_the_single_process_shards(tmp_path, cfg):
+    """cfg4 (the per-GPU shard of BASELINE configs 4 / 5: three blocks, 4096 two-env tasks on 2048 resident workgroups) takes the work queue, the gather
+    and the reset of finished envs in one process pair."""
     two = tmp_path / "two.npy"
-    line = _bench(["--gpus", "2", "--rehearse-on-one-gpu", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--dump-step", str(two)])
+    common = ["--config", cfg, "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-capacity"]
+    line = _bench(["--gpus", "2", "--rehearse-on-one-gpu"] + common + ["--dump-step", str(two)])
+    assert cfg in line["config"]["workload"] and line["config"]["gather_mode"] == "in line (closed loop)"
     assert line["n_gpus"] == 2 and line["steps"] == 2 and line["warmup"] == 1 and line["scaling"] == "weak"
     assert line["config"]["global_envs"] == 16384 and line["config"]["envs_per_gpu"] == 8192
     assert "gloo (rehearsal)" in line["config"]["parallelism"] and "2 ranks" in line["config"]["parallelism"]
     assert line["value"] > 0 and line["config"]["bad_envs"] == 0
-    assert line["roofline"]["launches_timed"] == 2 and line["roofline"]["traffic_source"]
+    assert line["roofline"]["launches_timed"] == 2 and (cfg != "cfg3" or line["roofline"]["traffic_source"])
     g = np.load(two)
     nobs = g.shape[1] - 2
     assert g.shape[0] == 16384 and np.isfinite(g).all()
     # each rank's rows of the gathered buffer == a one-rank run of the same global env ids (inputs are keyed by the shard's offset)
     for r in (0, 1):
         one = tmp_path / f"one{r}.npy"
-        l1 = _bench(["--gpus", "1", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--env-offset", str(8192 * r), "--dump-step", str(one)])
+        l1 = _bench(["--gpus", "1"] + common + ["--env-offset", str(8192 * r), "--dump-step", str(one)])
+        assert l1["config"]["gather_mode"] is None
         assert l1["n_gpus"] == 1 and l1["config"]["global_envs"] == 8192
         o = np.load(one)
         assert o.shape == (8192, nobs + 2)

@@ -184,3 +184,54 @@ def test_openai_obs_type_shapes(models):
     assert np.allclose(obs[:, 0:3], env.gripper_pos(), atol=1e-6) and np.allclose(obs[:, 3:6], env.block_pos(), atol=1e-6)
     with pytest.raises(ValueError):
         make_env(models, "cfg2", 1, obs_type="openai")                                # no finger joints among the DOFs
+
+
+def test_control_loop_on_the_stand_in(models, capsys):
+    """hsr/control.py:48-76 on the product's driver (hsr_env_amd/control.py): ControlHSREnv.control_agent steps with the zero action and returns
+    `done`; the loop resets the finished envs by mask and goes on.  Geofence .5 around the goal covers the pan (README.md:5 uses the same
+    value), so every env finishes on its first substep and is reset before the next env-step."""
+    from hsr_env_amd import control
+    m = models["cfg2"]
+    goal_space = Box(low=[-.1, -.2, .422], high=[.1, .2, .422])
+    block_space = Box(low=[-.1, -.2, .422, -3.14], high=[.1, .2, .422, 3.14])
+    env = control.ControlHSREnv(model=m, n_envs=4, sim=OracleBatchSim(m, 4), goals=[GoalSpec("block0", goal_space, 0.5)], block_space=block_space, steps_per_action=300)
+    env.seed(1)
+    env.reset()
+    t = env.control_agent()
+    assert t.shape == (4,) and t.all()
+    resets = []
+    orig = env.reset
+    env.reset = lambda mask=None: (resets.append(np.array(mask).copy()), orig(mask=mask))[1]
+    k, dt = control.run(env, env_steps=3)
+    assert k == 3 and len(resets) == 2 and all(r.all() for r in resets)        # no reset before the first env-step (done starts False), one before each of the others
+    line = capsys.readouterr().out.strip().splitlines()[-1]
+    assert line.startswith("3 env-steps x 4 envs in ") and line.endswith("env-steps/s")
+    # a goal out of reach: nobody finishes, nothing is reset, 300 substeps each
+    env2 = control.ControlHSREnv(model=m, n_envs=2, sim=OracleBatchSim(m, 2), goals=[GoalSpec("block0", np.array([.4, 0, .422]), 0.05)], steps_per_action=20)
+    env2.reset()
+    resets2 = []
+    orig2 = env2.reset
+    env2.reset = lambda mask=None: (resets2.append(mask), orig2(mask=mask))[1]
+    control.run(env2, env_steps=2, random_actions=True)
+    assert not resets2
+    # N = 1 keeps the reference's scalar shapes through the same loop
+    env1 = control.ControlHSREnv(model=models["cfg1"], n_envs=1, sim=OracleBatchSim(models["cfg1"], 1), goals=None, starts={}, steps_per_action=5)
+    env1.reset()
+    assert env1.control_agent() is False
+    control.run(env1, env_steps=2)
+
+
+def test_readme_command_line_selects_baseline_config_1(models):
+    """README.md:5 / BASELINE config 1: the reference's literal flags parse into the slide_x / slide_y model without a block and no goal."""
+    import argparse
+    parser = argparse.ArgumentParser()
+    wrapper_parser = parser.add_argument_group('wrapper_args')
+    env_parser = parser.add_argument_group('env_args')
+    util.add_env_args(env_parser)
+    util.add_wrapper_args(wrapper_parser)
+    argv = ["--block-space", "(0,0)(0,0)(0,0)(0,0)", "--steps-per-action=300", "--geofence=.5", "--goal-space", "(0,0)(0,0)(0,0)", "--use-dof", "slide_x", "--use-dof", "slide_y"]
+    args = util.hierarchical_parse_args(parser, argv)
+    got = {}
+    util.env_wrapper(lambda env_args, **kw: got.update(env_args))(**args)
+    assert got["steps_per_action"] == 300 and got["goals"] is None and got["block_space"] is None
+    assert got["model"].nv == 2 and got["model"].nu == 2 and not got["model"].block_body()

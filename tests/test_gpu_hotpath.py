@@ -923,10 +923,11 @@ def test_work_queue_watchdog_flag_is_sticky(models):
     sim.close()
 
 
-@pytest.mark.parametrize("cfg,n", [("cfg1", 1), ("cfg2", 4096), ("cfg3", 8192), ("cfg4", 8192), ("cupboard", 8192)])
+@pytest.mark.parametrize("cfg,n", [("cfg1", 1), ("cfg2", 4096), ("cfg3", 8192), ("cfg4", 8192), ("cfg4", 32768), ("cupboard", 8192)])
 def test_full_size_invariants(models, cfg, n):
     """BASELINE configs 1-3 at their OWN sizes (1 env; 4096 envs x 1 block, slides only; 8192 envs, all DOFs), the per-GPU shard of configs 4 / 5 (8192 envs x 3
-    blocks: 4096 two-env tasks through the work queue, the 32-env replay without it) and the cupboard scene, on the bench's inputs, two
+    blocks: 4096 two-env tasks through the work queue, the 32-env replay without it), config 4's TOTAL size on one GPU (32768 envs x 3 blocks: 16384 tasks through
+    the queue - what its four shards compute, env for env, since an env's result does not depend on the batch it runs in) and the cupboard scene, on the bench's inputs, two
     env-steps of 300 substeps with the goal test and the reset of finished envs in between, through properties that do not depend on the
     size: every env finite and unflagged, unit quaternions, blocks between floor and ceiling, reward == done and every finished env really
     inside the geofence, 300 substeps run unless finished; the run is deterministic (a second batch on the same inputs is bit-identical); envs
