@@ -865,7 +865,9 @@ template <int W = 1> __device__ bool mpr_penetration(const Geom &G1, const Geom 
             // triangle of that face, however the run got there.  Where it does not, libccd measures to the triangle's edge and the answer
             // depends on the triangle: a warm-started run then starts over from scratch, so that it ends where libccd's own search does
             // (as far as single precision follows it).
+#ifndef HSR_MPR_NO_RESTART
             if (!interior && warm_ok) { warm_ok = false; dir = normalized(-p0.v); goto cold_start; }
+#endif
             if (interior) {
                 // the witness is the foot of the perpendicular: depth = |n . v1|, direction = +-n
                 const float dn = dot(dir, p1.v);

@@ -358,7 +358,7 @@ static int upload_i(hsr_batch *b, const int **dst, const hsr_model *m, const cha
     const int *src = m->i32(name, &cnt);
     if (!src) return fail(HSR_EBLOB, "blob entry '%s' missing", name);
     int *d;
-    int rc = dalloc(b, &d, cnt ? cnt : 1);
+    int rc = dalloc(b, &d, cnt + 16);          // zero padding: the solver reads pair_slot in rows of eight (solve_body.inc, E2)
     if (rc) return rc;
     if (cnt) HIPCHK(hipMemcpy(d, src, cnt * sizeof(int), hipMemcpyHostToDevice));
     *dst = d;

@@ -504,7 +504,10 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
                 // hulls are scanned along d and the margin is refreshed; MPR runs only when d no longer separates - from the portal of the
                 // previous substep if the pair penetrated then (margin row = -1: rows 0-2 hold its vertex ids).
                 {
-                    constexpr int MW = 8;
+#ifndef HSR_MW
+#define HSR_MW 8
+#endif
+                    constexpr int MW = HSR_MW;
                     const bool cv = fn == FN_CONVEX;
                     float cdx = 0.f, cdy = 0.f, cdz = 0.f, cmg = 0.f;
                     int cfresh = 0;
