@@ -70,7 +70,69 @@ struct Kin2 {
     m3 R;
     v3 p, w, al, u, g;
 
-    // A: the link in its parent's frame -> recL; levels <= 1 are already world poses
+    // A: the link in its parent's frame -> recL; levels <= 1 are already world poses.
+    // Two rounds of LDS reads, both issued whole before anything is computed - the link's record with its three joint records, then the free joint's
+    // seven coordinates and the three joint coordinates (a record beyond the link's dofnum repeats joint 0: a valid address, an unused value) - instead of
+    // a loop whose every turn read a joint record and then the coordinate it names.  The joint loop is unrolled over the three joint slots a link can
+    // have; a slot no link of the wave uses, and the hinge arm of a slot without a hinge, are skipped wave-uniformly; the slide arm (twelve
+    // instructions) and the selects run unconditionally.  Same arithmetic as before, term by term: results are bit-identical.
+#ifndef HSR_KIN_A_OLD
+    __device__ __forceinline__ void stageA(const float *kc, int nlink, int c_, float *qposL, float *recL) {
+        c = c_; isl = c < nlink;
+        K = kc + KIN2_FLOATS * (isl ? c : 0);
+        const float4 h0 = kl4(K), h1 = kl4(K + 4), lp = kl4(K + 8), m0 = kl4(K + 12), m1 = kl4(K + 16), m2 = kl4(K + 20);
+        float4 ja[3], jb[3];
+#pragma unroll
+        for (int j = 0; j < 3; j++) { ja[j] = kl4(K + 36 + 8 * j); jb[j] = kl4(K + 40 + 8 * j); }
+        d0 = (int)h0.x; dn = (int)h0.y; free_ = (int)h0.z;
+        const int qadr = (int)h0.w;
+        mass = h1.z; anc = __float_as_uint(h1.w);
+        float qf[7], qj[3];
+#pragma unroll
+        for (int i = 0; i < 7; i++) qf[i] = qposL[qadr + i];          // (a link without a free joint reads its neighbours' coordinates: in bounds, not used)
+#pragma unroll
+        for (int j = 0; j < 3; j++) qj[j] = qposL[(int)ja[j].x];
+        // the chain of scalar joints
+        v3 pc = mk3(lp.x, lp.y, lp.z);
+        m3 Rc;
+        Rc.a[0] = m0.x; Rc.a[1] = m0.y; Rc.a[2] = m0.z; Rc.a[3] = m0.w; Rc.a[4] = m1.x; Rc.a[5] = m1.y; Rc.a[6] = m1.z; Rc.a[7] = m1.w; Rc.a[8] = m2.x;
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const bool on = !free_ && j < dn;
+            if (!wave_any(on)) continue;
+            const bool hinge = on && (int)ja[j].y != DOF_SLIDE;
+            const v3 ax = mk3(ja[j].z, ja[j].w, jb[j].x);
+            const v3 ps = pc + mulmv(Rc, ax) * qj[j];
+            v3 ph = pc;
+            m3 Rh = Rc;
+            if (wave_any(hinge)) {
+                const v3 jp = mk3(jb[j].y, jb[j].z, jb[j].w);
+                const v3 anchor = pc + mulmv(Rc, jp);
+                float sn, cs;
+                fast_sincos(0.5f * qj[j], &sn, &cs);
+                q4 qr;
+                qr.w = cs; qr.x = ax.x * sn; qr.y = ax.y * sn; qr.z = ax.z * sn;
+                Rh = mulmm(Rc, q2m(qr));
+                ph = anchor - mulmv(Rh, jp);
+            }
+            pc = sel3(hinge, ph, sel3(on, ps, pc));
+#pragma unroll
+            for (int k = 0; k < 9; k++) Rc.a[k] = hinge ? Rh.a[k] : Rc.a[k];
+        }
+        p = pc; R = Rc;
+        if (wave_any(free_ != 0)) {
+            q4 q;
+            q.w = qf[3]; q.x = qf[4]; q.y = qf[5]; q.z = qf[6];
+            q = qnormalized(q);                                      // mj_kinematics normalises in place
+            if (isl && free_) { qposL[qadr + 3] = q.w; qposL[qadr + 4] = q.x; qposL[qadr + 5] = q.y; qposL[qadr + 6] = q.z; }
+            const m3 Rf = q2m(q);
+            p = sel3(free_ != 0, mk3(qf[0], qf[1], qf[2]), pc);
+#pragma unroll
+            for (int k = 0; k < 9; k++) R.a[k] = free_ ? Rf.a[k] : Rc.a[k];
+        }
+        if (isl) pose_store(recL + 12 * c, R, p);
+    }
+#else
     __device__ __forceinline__ void stageA(const float *kc, int nlink, int c_, float *qposL, float *recL) {
         c = c_; isl = c < nlink;
         K = kc + KIN2_FLOATS * (isl ? c : 0);
@@ -108,6 +170,7 @@ struct Kin2 {
         }
         if (isl) pose_store(recL + 12 * c, R, p);
     }
+#endif
     // B: world pose = T(root) ... T(parent) T(self); the world's own transform is the identity, so lanes with fewer ancestors
     // multiply by it (exactly) instead of leaving the loop
     __device__ __forceinline__ void stageB(int maxdepth, const float *recL, float *poseL) {

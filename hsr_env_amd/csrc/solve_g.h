@@ -199,6 +199,9 @@ template <int G> __device__ __forceinline__ bool chol_pivots_ok(float invd) {
     return gmax<G>(badp ? 1 : 0) == 0;
 }
 template <int G, int NK = G> __device__ __forceinline__ bool chol_g(float (&row)[G], float &invd, int nv, int ndense, int c) {
+#ifndef HSR_CHOL_MASKS
+    asm volatile("" : "+v"(c));          // lane masks formed where they are used, not hoisted out of the caller's loops as spilled SGPR pairs (chol_g_fwd)
+#endif
     invd = 1.f;
     static_for<0, NK>([&](auto jc) {
         constexpr int j = decltype(jc)::value;
@@ -227,6 +230,11 @@ template <int G, int NK = G> __device__ __forceinline__ bool chol_g_fwd(float (&
     invd = 1.f;
     float sacc = b;
     y = 0.f;
+#ifndef HSR_CHOL_MASKS
+    // the lane id is laundered per call: the thirteen `c == j` masks are then formed where they are used (one v_cmp each) instead of being hoisted out of
+    // the Newton loop as SGPR pairs, spilled into VGPR lanes and read back with two v_readlane per step
+    asm volatile("" : "+v"(c));
+#endif
     static_for<0, NK>([&](auto jc) {
         constexpr int j = decltype(jc)::value;
         if (j < nv) {
@@ -242,7 +250,11 @@ template <int G, int NK = G> __device__ __forceinline__ bool chol_g_fwd(float (&
                 constexpr int i = decltype(ic)::value;
                 fmac_bcast<G, i, bc_first<G, i, j + 1>()>(row[i], nl, bl);
             });
+#ifndef HSR_CHOL_MASKS
+            fmac_bcast<G, j, true>(sacc, nl, bc_prepare<G>(t));      // sacc -= L[c][j] y_j (a lane c <= j has taken its y already: what lands in its sacc is never read)
+#else
             fmac_bcast<G, j, true>(sacc, c > j ? nl : 0.f, bc_prepare<G>(t));      // sacc -= L[c][j] y_j
+#endif
         }
     });
     return chol_pivots_ok<G>(invd);
@@ -296,6 +308,9 @@ struct HessAcc32 {
 // matrix M and M + h D of a robot followed by free bodies with principal-axis inertia: ND pivot steps with updates of the first ND
 // rows only, and every tail lane takes the reciprocal root of its own diagonal entry (diag: lane c's M[c][c]; 1 for the padding lanes).
 template <int G, int NK, int ND> __device__ __forceinline__ bool chol_g_tail(float (&row)[G], float &invd, float diag, int c) {
+#ifndef HSR_CHOL_MASKS
+    asm volatile("" : "+v"(c));          // lane masks formed where they are used, not hoisted out of the caller's loops as spilled SGPR pairs (chol_g_fwd)
+#endif
     invd = 1.f;
     static_for<0, ND>([&](auto jc) {
         constexpr int j = decltype(jc)::value;
