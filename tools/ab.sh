@@ -6,7 +6,7 @@ KEXPR=""
 if [ "$1" == "-t" ]; then KEXPR="$2"; shift; shift; fi
 for v in "$@"; do
   if [ -n "$KEXPR" ]; then HSR_LIB=$PWD/hsr_env_amd/var_${v}.so python -m pytest tests -m gpu -x -q -k "$KEXPR" > $OUT/ab_${v}_tests.log 2>&1; echo "rc=$?" >> $OUT/ab_${v}_tests.log; fi
-  HSR_LIB=$PWD/hsr_env_amd/var_${v}.so python bench.py --steps 10 --warmup 3 --no-cpu-baseline --config ${HSR_CFG:-cfg3} > $OUT/ab_${v}_bench.log 2>&1 || exit 1
+  HSR_LIB=$PWD/hsr_env_amd/var_${v}.so python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-capacity --config ${HSR_CFG:-cfg3} > $OUT/ab_${v}_bench.log 2>&1 || exit 1
   [ -f hsr_env_amd/var_${v}_l.so ] && HSR_LIB=$PWD/hsr_env_amd/var_${v}_l.so python tools/block_life.py > $OUT/ab_${v}_life.log 2>&1
   [ -f hsr_env_amd/var_${v}_t.so ] && HSR_LIB=$PWD/hsr_env_amd/var_${v}_t.so python tools/block_times.py > $OUT/ab_${v}_bt.log 2>&1
   python - $v <<'PY'
