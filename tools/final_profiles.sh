@@ -1,7 +1,7 @@
 #!/bin/bash
 # Evidence of a round on the GPU box in one call: rocprofv3 kernel-trace stats + PMC passes (tools/profile_round.sh), workgroup lifetimes of the
 # product kernel for the five configurations (libhsrsim_life.so), the phase profile of cfg3 / cfg4 (libhsrsim_timing.so).  usage: tools/final_profiles.sh TAG
-TAG=${1:-r04}
+TAG=${1:-r05}
 mkdir -p gpurun_out/r5
 export TMPDIR=/tmp
 bash tools/profile_round.sh $TAG > gpurun_out/r5/final_profile_round.log 2>&1 || { echo "profile_round failed"; tail -5 gpurun_out/r5/final_profile_round.log; exit 1; }

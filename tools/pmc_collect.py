@@ -84,7 +84,7 @@ try:
                                   "mean_ms_bench_hip_events_same_run": round(b["roofline"]["kernel_ms_mean"], 3), "bench_value_same_run": round(b["value"], 1)}
 except Exception as ex:           # a missing trace is not an error of the PMC summary
     summary["_timed_launches"] = {"error": str(ex)}
-summary["_note"] = (f"{tag}, commit {commit}{' + uncommitted changes' if dirty else ''}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_* in separate passes (with --kernel-trace only), python3 bench.py --steps 1 "
+summary["_note"] = (f"{tag}, commit {commit}{' + uncommitted changes' if dirty else ''}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_* in separate passes (with --kernel-trace only), python3 bench.py --steps 1 --no-capacity "
                     "--warmup 3 --no-cpu-baseline (cfg3, 8192 envs; k_env_step_mf: the fourth, timed launch only); bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 per the gfx950 correction of "
                     "MI355X_MICROARCH.md; k_env_step_mf: one launch = 300 substeps of 8192 envs (algorithmic 630 MB) including ctrl in and obs / reward / done out; narrow accesses are uncalibrated")
 (prof / "pmc_summary.json").write_text(json.dumps(summary, indent=1))
