@@ -859,7 +859,7 @@ extern "C" int hsr_batch_set_persistent(hsr_batch *b, int on) {
     return b->persist ? 1 : 0;
 }
 extern "C" int hsr_batch_is_persistent(const hsr_batch *b) { NULLCHK(b); return b->persist ? 1 : 0; }
-extern "C" int hsr_batch_set_debug(hsr_batch *b, int on) { if (!b) return fail(HSR_EINVAL, "null batch"); b->debug_store = (on & 1) != 0; b->test_hooks = on & (6 | 16 | 32 | 64); return HSR_OK; }
+extern "C" int hsr_batch_set_debug(hsr_batch *b, int on) { if (!b) return fail(HSR_EINVAL, "null batch"); b->debug_store = (on & 1) != 0; b->test_hooks = on & (6 | 16 | 32 | 64 | 128); return HSR_OK; }
 extern "C" int hsr_batch_set_schedule(hsr_batch *b, int on) { NULLCHK(b); b->schedule = on != 0; return HSR_OK; }
 extern "C" int hsr_batch_set_mpr_warm(hsr_batch *b, int on) {
     NULLCHK(b);

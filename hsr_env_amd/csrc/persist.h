@@ -120,6 +120,8 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
     const int mode = 1, debug = 0;
     const bool dbg_store = flags & 1;          // introspection: contact counts / solver counters of each env's last substep go to global memory
     const bool hook_jv_per_contact = flags & 2, hook_majorant = flags & 4;      // tests: force the J v per contact / the PSD-majorant Newton step
+    const bool hook_dense_chol = flags & 128;         // tests: the dense factorisation of the Newton Hessian even where the sparse one applies
+    constexpr bool EXACT_CT = EXACT && !std::is_same<MT, DevModel>::value;      // sizes AND structure (nfb, ndense) known at compile time
     const bool hook_no_item_list = flags & 64;        // tests: cull every substep (the behaviour before the item list was kept over substeps)
     const bool hook_ignore_stamps = flags & 16;      // tests: trust a separation margin whatever its stamp (the behaviour before the stamps existed)
     const bool mpr_warm = !(flags & 8);       // the portal of a penetrating convex pair is carried to its next substep (hsr_batch_set_mpr_warm)

@@ -259,6 +259,133 @@ template <int G, int NK = G> __device__ __forceinline__ bool chol_g_fwd(float (&
     });
     return chol_pivots_ok<G>(invd);
 }
+// SPARSE factorisation (round 5, 32-lane instances with several free bodies): H of a robot (dofs 0 .. ND - 1) followed by NB free bodies of six dofs.  `merged` (wave-uniform): every
+// env of the wave couples AT MOST ONE body to the robot and no body to another (checked per substep by the caller; 99 % of the env-substeps of cfg4, 95 % of those of its hardest
+// tasks); otherwise the bodies' columns are eliminated one by one with all their updates - the dense algorithm, sharing the robot's steps.  Eliminating the robot's columns first then fills nothing outside (robot + that body)^2: the three bodies' blocks stay independent of each other, so after the ND dense steps
+// (whose updates still cover every body column - exact zeros for the bodies the robot does not touch; which body it touches is not known at compile time) dof t of EVERY body is
+// eliminated in one step: a lane works on its own body's pivot column (its entry selected out of the NB column registers, the pivot fetched with one ds_bpermute whose source lane
+// depends on the lane's body), one rsq, and the updates of the body's remaining columns with the multiplier masked per body (a lane of another body must not pick up a product of
+// two different bodies' columns in what is ITS lower triangle).  ND + 6 dependent steps and ND (12 + ..) + 6 (19 + 3 t') instructions instead of NK steps of 12 + (NK - 1 - j):
+// about 400 instead of 650 for ND = 7, NB = 3 - the factorisation is issue-bound (the arrow experiment), so it is the instruction count that pays.
+// Same contract as chol_g_fwd: lane c ends with row c of L in row[0 .. c], invd = 1 / L[c][c], y = the forward substitution L y = b.  fb / kk: the lane's body (-1: robot) and dof in it.
+template <int G, int NK, int ND> __device__ __forceinline__ bool chol_sparse_fwd(float (&row)[G], float &invd, int c, float b, float &y, int fb, int kk, bool merged) {
+    constexpr int NB = (NK - ND) / 6;
+    static_assert(G == 32, "two DPP rows per env: the own-body broadcasts go through ds_bpermute");
+    asm volatile("" : "+v"(c));
+    asm volatile("" : "+v"(fb));
+    invd = 1.f; y = 0.f;
+    float sacc = b;
+    static_for<0, ND>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        const float ajj = gbcast_after_asm<G, j>(row[j]);
+        const float inv = __builtin_amdgcn_rsqf(ajj);
+        const float lcj = row[j] * inv;
+        const float t = sacc * inv;
+        if (c == j) { invd = inv; y = t; }
+        row[j] = lcj;
+        const float nl = -lcj;
+        const BcSrc<G> bl = bc_prepare<G>(lcj);
+        static_for<j + 1, NK>([&](auto ic) { constexpr int i = decltype(ic)::value; fmac_bcast<G, i, bc_first<G, i, j + 1>()>(row[i], nl, bl); });
+        fmac_bcast<G, j, true>(sacc, nl, bc_prepare<G>(t));
+    });
+    if (!merged) {          // wave-uniform: some env of the wave couples two bodies (to each other, or both to the robot) - the bodies' columns one by one, all updates, as chol_g_fwd does
+        static_for<ND, NK>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            const float ajj = gbcast_after_asm<G, j>(row[j]);
+            const float inv = __builtin_amdgcn_rsqf(ajj);
+            const float lcj = row[j] * inv;
+            const float t = sacc * inv;
+            if (c == j) { invd = inv; y = t; }
+            row[j] = lcj;
+            const float nl = -lcj;
+            const BcSrc<G> bl = bc_prepare<G>(lcj);
+            static_for<j + 1, NK>([&](auto ic) { constexpr int i = decltype(ic)::value; fmac_bcast<G, i, bc_first<G, i, j + 1>()>(row[i], nl, bl); });
+            fmac_bcast<G, j, true>(sacc, nl, bc_prepare<G>(t));
+        });
+        return chol_pivots_ok<G>(invd);
+    }
+    const int fbc = fb < 0 ? 0 : fb;                                     // (a robot lane follows body 0: its registers above the diagonal are never read)
+    const int pl0 = 4 * ((threadIdx.x & 32) + ND + 6 * fbc);            // byte address of the lane that holds dof 0 of this lane's body
+    static_for<0, 6>([&](auto tc) {
+        constexpr int t = decltype(tc)::value;
+        float mine = row[ND + t];
+        static_for<1, NB>([&](auto bc_) { constexpr int bb = decltype(bc_)::value; mine = fb == bb ? row[ND + 6 * bb + t] : mine; });
+#ifdef HSR_SPARSE_READLANE
+        // (the pivot of the lane's own body by NB readlane broadcasts and a select instead of one ds_bpermute with a per-lane source: measured, no faster)
+        float ajj = gbcast_after_asm<G, ND + t>(row[ND + t]);
+        static_for<1, NB>([&](auto bc_) { constexpr int bb = decltype(bc_)::value; const float a_ = gbcast_after_asm<G, ND + 6 * bb + t>(row[ND + 6 * bb + t]); ajj = fb == bb ? a_ : ajj; });
+#else
+        const float ajj = __int_as_float(__builtin_amdgcn_ds_bpermute(pl0 + 4 * t, __float_as_int(mine)));
+#endif
+        const float inv = __builtin_amdgcn_rsqf(ajj);
+        const float l = mine * inv;
+        const float tz = sacc * inv;
+        if (kk == t && fb >= 0) { invd = inv; y = tz; }
+        static_for<0, NB>([&](auto bc_) { constexpr int bb = decltype(bc_)::value; row[ND + 6 * bb + t] = fbc == bb ? l : row[ND + 6 * bb + t]; });
+        if constexpr (t < 5) {
+            float nlb[NB];
+            static_for<0, NB>([&](auto bc_) { constexpr int bb = decltype(bc_)::value; nlb[bb] = fb == bb ? -l : 0.f; });
+            const BcSrc<G> bl = bc_prepare<G>(l);
+            static_for<0, NB>([&](auto bc_) {
+                constexpr int bb = decltype(bc_)::value;
+                static_for<t + 1, 6>([&](auto sc) { constexpr int k = ND + 6 * bb + decltype(sc)::value; fmac_bcast<G, k, (bb == 0 && k == ND + t + 1) || k == 16>(row[k], nlb[bb], bl); });
+            });
+        }
+#ifdef HSR_SPARSE_READLANE
+        float zt = gbcast<G, ND + t>(tz);
+        static_for<1, NB>([&](auto bc_) { constexpr int bb = decltype(bc_)::value; const float z_ = gbcast<G, ND + 6 * bb + t>(tz); zt = fb == bb ? z_ : zt; });
+        (void)pl0;
+#else
+        const float zt = __int_as_float(__builtin_amdgcn_ds_bpermute(pl0 + 4 * t, __float_as_int(tz)));
+#endif
+        sacc = __builtin_fmaf(-l, zt, sacc);                             // sacc -= L[c][j] y_j, j = this lane's body's dof t
+    });
+    return chol_pivots_ok<G>(invd);
+}
+// ... and L^T x = y for such a factor, last dof first: the bodies side by side, two dofs per reduction latency (a body's column sums over the body's own later rows only - every other lane
+// holds an exact zero there), then the robot's columns as in chol_back_mf (they sum over the robot's later rows and the coupled body's).
+template <int G, int NK, int ND> __device__ __forceinline__ float chol_sparse_back(const float (&row)[G], float invd, float y, int c, bool merged) {
+    constexpr int NB = (NK - ND) / 6;
+    asm volatile("" : "+v"(c));
+    float nlo[G];
+#pragma unroll
+    for (int k = 0; k < NK; k++) nlo[k] = (k < c) ? -row[k] : 0.f;
+    float x = 0.f;
+    if (!merged) {          // the bodies' columns pair by pair, last first (chol_back_mf's order)
+        static_for<0, (NK - ND) / 2>([&](auto jc) {
+            constexpr int j = NK - 1 - 2 * decltype(jc)::value;
+            const float A = gsum<G>(nlo[j] * x), B = gsum<G>(nlo[j - 1] * x);
+            const float xj = (y + A) * invd;
+            if (c == j) x = xj;
+            const float t = gbcast<G, j>(nlo[j - 1] * xj);
+            if (c == j - 1) x = (y + B + t) * invd;
+        });
+    } else
+    static_for<0, 3>([&](auto sc) {
+        constexpr int s1 = 5 - 2 * decltype(sc)::value;                  // dofs s1 and s1 - 1 of every body
+        float A[NB > 0 ? NB : 1], B[NB > 0 ? NB : 1];
+        static_for<0, NB>([&](auto bc_) { constexpr int bb = decltype(bc_)::value, j = ND + 6 * bb + s1; A[bb] = gsum<G>(nlo[j] * x); B[bb] = gsum<G>(nlo[j - 1] * x); });
+        float xn = x;
+        static_for<0, NB>([&](auto bc_) {
+            constexpr int bb = decltype(bc_)::value, j = ND + 6 * bb + s1;
+            const float xj = (y + A[bb]) * invd;
+            if (c == j) xn = xj;
+            const float t = gbcast<G, j>(nlo[j - 1] * xj);
+            if (c == j - 1) xn = (y + B[bb] + t) * invd;
+        });
+        x = xn;
+    });
+    static_for<0, ND / 2>([&](auto jc) {
+        constexpr int j = ND - 1 - 2 * decltype(jc)::value;              // columns j and j - 1
+        const float A = gsum<G>(nlo[j] * x), B = gsum<G>(nlo[j - 1] * x);
+        const float xj = (y + A) * invd;
+        if (c == j) x = xj;
+        const float t = gbcast<G, j>(nlo[j - 1] * xj);
+        if (c == j - 1) x = (y + B + t) * invd;
+    });
+    if constexpr (ND % 2 == 1) { const float tot = gsum<G>(nlo[0] * x); if (c == 0) x = (y + tot) * invd; }
+    return x;
+}
 // Accumulator of v_mfma_f32_16x16x1f32 (4 blocks of 16x16, K = 1; layouts measured with tools/micro/mfma_layout.hip): operand A / B of lane l
 // is row / column l % 16 of block l / 16; result register v of lane l is block v / 4, row 4 (l / 16) + v % 4, column l % 16.  add_rows:
 // the 4x4 transposition of (lane row, register group) - eight v_permlane32_swap, eight v_permlane16_swap - leaves block b in the 16

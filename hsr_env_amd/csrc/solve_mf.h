@@ -213,7 +213,7 @@ __global__ void __launch_bounds__(64, 2) k_solve_mf(DevModel m, DevState s, int 
     constexpr int NDK = -1;                // ... and the run-time ndense
     constexpr bool REP = false;            // (solo-server replicas: persistent kernel only)
     using MT = DevModel;                  // (the chain kernel reads every model field at run time)
-    constexpr bool hook_jv_per_contact = false, hook_majorant = false;
+    constexpr bool hook_jv_per_contact = false, hook_majorant = false, hook_dense_chol = false, EXACT_CT = false;
     constexpr int nfb = 0;                 // the per-substep chain keeps the per-contact Hessian assembly (no scratch for the per-body one)
     float *fbK = nullptr;
 #define SOLVE_STORE_DIAG true

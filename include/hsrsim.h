@@ -129,7 +129,7 @@ int hsr_batch_is_persistent(const hsr_batch *b);
  * kernel (2: J v per contact instead of per link; 4: every iteration takes the PSD-majorant Hessian) - same minimiser, other path;
  * 16 makes the convex-pair section trust a cached separation margin whatever its stamp - the round-2 behaviour, kept so that the test of
  * the stamps can show what they prevent; 64 makes the persistent kernel cull every substep instead of keeping its narrowphase item list
- * until a geom may have moved half a skin (the behaviour up to round 3; the contact sets are the same either way); 32 raises the work queue's watchdog flag after every persistent launch (what a ticket that is
+ * until a geom may have moved half a skin (the behaviour up to round 3; the contact sets are the same either way); 128 keeps the dense factorisation of the Newton Hessian where the sparse one applies (32-lane instances with several free bodies, envs whose contacts couple at most one body to the robot: same minimiser, fewer instructions); 32 raises the work queue's watchdog flag after every persistent launch (what a ticket that is
  * never served does): the flag is sticky on the device, the next synchronising call (hsr_batch_sync, _step, _kernel_times, _cap_counts,
  * _bad_state, _get_state) returns HSR_EDEVICE once and clears it. */
 int hsr_batch_set_debug(hsr_batch *b, int on);

@@ -153,6 +153,64 @@ def test_per_body_hessian_equals_per_contact_assembly(models, monkeypatch):
     assert not unexplained, unexplained
 
 
+def test_sparse_factorisation_equals_the_dense_one(models):
+    """cfg4 (robot + three blocks): in an env whose contacts couple at most one block to the robot and no block to another - 99 % of the env-substeps, 95 % of those of
+    the hardest tasks - the Newton Hessian is factored with the robot's seven dense steps and then dof t of every block at once (solve_g.h chol_sparse_fwd / chol_sparse_back:
+    13 dependent steps and ~400 instructions instead of 25 and ~650); test hook 128 keeps the dense factorisation.  Three batches - blocks apart (the robot touches none or
+    one), a finger pushed into a block (one block coupled to the robot), two blocks pushed into each other (dense fallback, decided per env: next to envs of the same wave
+    that take the sparse path) - one substep and then twenty more: both paths must agree BIT FOR BIT (same arithmetic on the entries that are not structurally zero); the
+    single substep of the first batch must follow the oracle like every other single-substep test."""
+    m = models["cfg4"]
+    n = 128
+    rng = np.random.default_rng(2025)
+    q, v, ctrl = random_states(m, n, rng)
+    pre = oracle_rollout(m, q, v, ctrl, 60)
+    qs, vs, ws = np.array([s.qpos for s in pre]), np.array([s.qvel for s in pre]), np.array([s.qacc_warmstart for s in pre])
+    a0, a1 = m.free_joint_qadrs()[:2]
+    qt = qs.copy()                                   # block 1 overlapping block 0 by 2 mm in every fourth env
+    qt[::4, a1:a1 + 3] = qt[::4, a0:a0 + 3] + np.array([0.048, 0.0, 0.0]); qt[::4, a1 + 3:a1 + 7] = qt[::4, a0 + 3:a0 + 7]
+    qf = qs.copy()                                   # block 0 dropped between the fingers in every other env (the pinch regime of cfg3, with two more blocks on the table)
+    bl, br = m.body_id("hand_l_distal_link"), m.body_id("hand_r_distal_link")
+    for e in range(0, n, 2):
+        o = OracleSim(m); o.qpos[:] = qf[e]; o.forward()
+        qf[e, a0:a0 + 3] = 0.5 * (o.body_xpos(bl) + o.body_xpos(br)) + rng.uniform(-0.01, 0.01, 3)
+        quat = rng.normal(size=4); qf[e, a0 + 3:a0 + 7] = quat / np.linalg.norm(quat)
+    for tag, qq in (("apart", qs), ("finger on a block", qf), ("blocks touching", qt)):
+        outs = []
+        for hook in (0, 128):
+            sim = hs.BatchSim(m, n)
+            sim.set_debug(1 | hook)
+            sim.set_warmstart(ws)
+            sim.set_state(np.zeros(n), qq, vs)
+            one = sim.step(ctrl, 1)[0].copy()
+            ncon, trips = sim.get_field(hs.F_NCON).copy(), sim.get_field(hs.F_NITER).copy()
+            more = sim.step(ctrl, 20)[0].copy()
+            assert not sim.bad_state()[0].any()
+            sim.close()
+            outs.append((one, more, ncon, trips))
+        (a1_, am, ncon, ta), (b1_, bm, _, tb) = outs
+        dv = np.abs(a1_[:, m.nq:] - b1_[:, m.nq:]) / (1 + np.abs(b1_[:, m.nq:]))
+        dm = np.abs(am - bm).max(axis=1)
+        print(f"sparse vs dense ({tag}): one substep max rel dqvel {dv.max():.1e}, after 20 more substeps median |dobs| {np.median(dm):.1e} p90 {np.percentile(dm, 90):.1e} max {dm.max():.1e}; "
+              f"Newton iterations differ in {int((ta != tb).sum())} of {n} envs (mean {ta.mean():.1f}); contacts per env mean {ncon.mean():.1f}")
+        # the sparse path performs the dense path's arithmetic on the structurally non-zero entries in the same order: BIT-IDENTICAL results - which is what allows the
+        # choice to be made per wave (an env's result must never depend on its neighbours)
+        assert dv.max() == 0.0 and dm.max() == 0.0 and (ta == tb).all(), (dv.max(), dm.max())
+        if tag == "apart":
+            unexplained = []
+            for e in range(n):
+                o = pre[e]
+                o.step()
+                d = (np.abs(a1_[e, m.nq:] - o.qvel) / (1 + np.abs(o.qvel))).max()
+                if not d < 1e-4 and int(ncon[e]) == o.ncon:
+                    unexplained.append((e, d))
+            assert not unexplained, unexplained
+        elif tag == "blocks touching":
+            assert int((ncon[::4] > ncon[1::4]).sum()) > n // 16           # the pushed-together blocks do touch
+        else:
+            assert int((ncon[::2] != ncon[1::2]).sum()) > n // 8            # the dropped block does meet the fingers
+
+
 @pytest.mark.parametrize("cfg", ["cfg3", "cfg4"])
 @pytest.mark.parametrize("hook", [2, 4])
 def test_rarely_taken_solver_branches(models, cfg, hook):
@@ -1182,7 +1240,7 @@ def test_solver_optimum_on_hard_states(models):
     constraint cost - found by scipy on a numpy restatement of the cost (tests/test_oracle_optimality.py: neither the oracle's cone routines nor its
     Newton solver are involved; the oracle only supplies M, J, aref, R of its forward pass at the same state).  States whose fp32 contact list differs
     from the fp64 one beyond the stage tolerances pose a different problem and are set aside (counted, bounded).  fp32 bounds: the scaled cost of the
-    HIP solution lies within 5e-6 (1 + |scaled cost|) of the minimum (fp32 resolves the cost itself to 6e-8 of its value), |qacc - a*| < 2e-2 + 2e-3 |a*| per dof in 95 % of the states (the tolerance of the substep test)."""
+    HIP solution lies within 1e-6 (1 + |scaled cost|) of the minimum (measured: median 9e-10, worst 3.8e-8; fp32 resolves the cost itself to 6e-8 of its value), |qacc - a*| < 2e-2 + 2e-3 |a*| per dof in 95 % of the states (the tolerance of the substep test)."""
     import test_oracle_optimality as too
     rows = list(too.load_states())
     by_cfg = {}
@@ -1217,5 +1275,5 @@ def test_solver_optimum_on_hard_states(models):
           f"median {np.median(excess):.1e} p90 {np.percentile(excess, 90):.1e} max {excess.max():.1e}; |qacc - a*| / (2e-2 + 2e-3 |a*|): median {np.median(rel):.2f} "
           f"p95 {np.percentile(rel, 95):.2f} max {rel.max():.2f}")
     assert total >= 200 and skipped <= 0.25 * total
-    assert excess.max() < 5e-6, excess.max()
+    assert excess.max() < 1e-6, excess.max()
     assert np.percentile(rel, 95) < 1.0, np.sort(rel)[-10:]

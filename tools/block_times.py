@@ -9,6 +9,8 @@ cfg = os.environ.get('HSR_CFG', 'cfg3')
 m = load_config(cfg); n = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
 q0, goal = sample_inputs(m, n, 0, 0)
 sim = hs.BatchSim(m, n); sim.set_graph(False)
+if os.environ.get('HSR_LIFE_QUEUE') == '0':
+    sim.set_queue(0)          # static assignment: a workgroup's stamps and counters are those of ONE task (cfg4 at 8192 envs would take the work queue)
 sim.reset(qpos0=q0, mocap=goal)
 rng = np.random.default_rng(1)
 for k in range(3):
@@ -47,6 +49,11 @@ if os.environ.get('HSR_LSCOUNT'):      # timing build with -DHSR_LSCOUNT: counte
     ev = a[:, 7] & 0xffffffff; itn = a[:, 7] >> 32
     print('line-search evaluations per Newton iteration (lane 0 env): all %.2f, slowest 20 %.2f (its iterations / substep %.2f), median 20 %.2f' % (
         ev.sum() / max(itn.sum(), 1), ev[o[-20:]].sum() / max(itn[o[-20:]].sum(), 1), itn[o[-20:]].mean() / 300, ev[o[nb // 2 - 10: nb // 2 + 10]].sum() / max(itn[o[nb // 2 - 10: nb // 2 + 10]].sum(), 1)))
+if os.environ.get('HSR_CPLSTAT'):      # timing build with -DHSR_CPLSTAT: counter 3 = substeps of lane 0's env by what its contacts couple
+    c0, c1, c2 = a[:, 7] & 0x1fffff, (a[:, 7] >> 21) & 0x1fffff, (a[:, 7] >> 42) & 0x1fffff
+    for nm, idx in (('all', o), ('slowest 20', o[-20:]), ('median 20', o[nb // 2 - 10: nb // 2 + 10])):
+        tot = max((c0[idx] + c1[idx] + c2[idx]).sum(), 1)
+        print('coupling of the contact list (lane 0 env), %s: no robot <-> body contact %.2f, one body coupled to the robot and no body <-> body %.2f, more %.2f' % (nm, c0[idx].sum() / tot, c1[idx].sum() / tot, c2[idx].sum() / tot))
 print('nefc sum / substep: mean %.2f, slowest 10 %s' % (a[:, 7].mean() / 300, (a[o[-10:], 7] / 300).round(2)))
 print('corr(life, newton) %.3f  corr(life, items) %.3f corr(life, nefc) %.3f' % (np.corrcoef(life, a[:, 4])[0, 1], np.corrcoef(life, a[:, 6])[0, 1], np.corrcoef(life, a[:, 7])[0, 1]))
 A = np.stack([np.ones(nb), a[:, 4], a[:, 6], a[:, 7]], 1).astype(np.float64)
