@@ -1137,6 +1137,31 @@ def test_solo_servers_follow_the_plain_run(models, cfg):
     assert np.median(err) < 1e-5 and np.percentile(err, 90) < 2e-3
 
 
+def test_solo_servers_stand_down_when_the_ticket_cannot_hold_the_substep(models):
+    """Round-4 advisor finding: a hand-over ticket packs `env | substep << 20` into one int that the server reads as "empty" when negative - with 2048 or more
+    substeps the substep field reaches the sign bit and an env handed over would never be run to the end.  hsr_batch_step now launches such an env-step without
+    servers: with servers requested and a threshold every env passes, 2100 substeps must complete (no hand-over, every env stepped 2100 times) and equal, bit
+    for bit, the run of a batch that never asked for servers (same queue settings)."""
+    m = models["cfg3"]
+    n = 64
+    rng = np.random.default_rng(52)
+    q, v, ctrl = random_states(m, n, rng)
+    outs = []
+    for servers in (0, n):
+        sim = hs.BatchSim(m, n)
+        if servers:
+            assert sim.set_solo(servers, 0.01)
+        sim.set_queue(1, 10)
+        sim.set_state(np.zeros(n), q, v)
+        obs, rew, done, ns = sim.step(ctrl, 2100)
+        assert (ns == 2100).all() and not sim.bad_state()[1]
+        if servers:
+            assert sim.solo_handovers() == 0
+        outs.append(obs.copy())
+        sim.close()
+    assert np.array_equal(outs[0], outs[1])
+
+
 @pytest.mark.parametrize("cfg", ["meshrest4", "meshrest1"])
 def test_plane_convex_contacts_match_oracle(models, cfg):
     """Plane <-> convex (round 4: several points per pair in meshrest4, the deepest one only in meshrest1): the head-pan hull dropped on the

@@ -49,6 +49,10 @@ if os.environ.get('HSR_LSCOUNT'):      # timing build with -DHSR_LSCOUNT: counte
     ev = a[:, 7] & 0xffffffff; itn = a[:, 7] >> 32
     print('line-search evaluations per Newton iteration (lane 0 env): all %.2f, slowest 20 %.2f (its iterations / substep %.2f), median 20 %.2f' % (
         ev.sum() / max(itn.sum(), 1), ev[o[-20:]].sum() / max(itn[o[-20:]].sum(), 1), itn[o[-20:]].mean() / 300, ev[o[nb // 2 - 10: nb // 2 + 10]].sum() / max(itn[o[nb // 2 - 10: nb // 2 + 10]].sum(), 1)))
+if os.environ.get('HSR_NOSTEPCOUNT'):      # timing build with -DHSR_NOSTEPCOUNT
+    ns_, tot_ = a[:, 7] & 0xffffffff, a[:, 7] >> 32
+    for nm, idx in (('all', o), ('slowest 20', o[-20:]), ('median 20', o[nb // 2 - 10: nb // 2 + 10]), ('fastest 20', o[:20])):
+        print('substeps whose first Newton iteration took no step in any env of the wave, %s: %.3f of %.1f substeps with an iteration' % (nm, ns_[idx].sum() / max(tot_[idx].sum(), 1), tot_[idx].mean()))
 if os.environ.get('HSR_CPLSTAT'):      # timing build with -DHSR_CPLSTAT: counter 3 = substeps of lane 0's env by what its contacts couple
     c0, c1, c2 = a[:, 7] & 0x1fffff, (a[:, 7] >> 21) & 0x1fffff, (a[:, 7] >> 42) & 0x1fffff
     for nm, idx in (('all', o), ('slowest 20', o[-20:]), ('median 20', o[nb // 2 - 10: nb // 2 + 10])):
