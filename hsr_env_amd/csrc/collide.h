@@ -658,7 +658,6 @@ template <class ST = NoStamp> __device__ __forceinline__ int collide_box_box_w8(
             P = mk3(scr[3 * sub], scr[3 * sub + 1], scr[3 * sub + 2]);
             __builtin_amdgcn_wave_barrier();
         };
-#ifndef HSR_NO_BB_FAST
         // Resting contact (the block on the table): the whole incident face lies inside the four side planes of the reference face.  The four
         // clips then copy the polygon unchanged - no vertex is outside (da <= 0 everywhere), so none is dropped and no edge is cut - and are
         // skipped; `side` is the very expression the clip evaluates.
@@ -666,7 +665,6 @@ template <class ST = NoStamp> __device__ __forceinline__ int collide_box_box_w8(
         const bool in4 = sub >= 4 || (side(Au, su) <= 0 && side(-Au, su) <= 0 && side(Av, sv) <= 0 && side(-Av, sv) <= 0);
         const bool all_in = (((unsigned)(__ballot(in4) >> (threadIdx.x & 56))) & 0xffu) == 0xffu;
         if (!all_in)
-#endif
         {
         clip(Au, su);
         if (np) clip(-Au, su);
@@ -719,16 +717,10 @@ __device__ int g_dbg_nsup_lane;   // unused placeholder to keep the symbol table
 #endif
 template <int W = 1> __device__ __forceinline__ Sup mpr_support(const Geom &G1, const Geom &G2, v3 dir) {
     Sup s;
-#ifndef HSR_MPR_COLD_ONLY
     int i1, i2;
     s.v1 = support<W>(G1, dir, &i1);
     s.v2 = support<W>(G2, -dir, &i2);
     s.id = i1 | (i2 << VID_BITS);
-#else
-    s.v1 = support<W>(G1, dir);
-    s.v2 = support<W>(G2, -dir);
-    s.id = 0;
-#endif
     s.v = s.v1 - s.v2;
     return s;
 }
@@ -801,7 +793,6 @@ template <int W = 1> __device__ bool mpr_penetration(const Geom &G1, const Geom 
     sep = mk3(0, 0, 0);
     nsup = 0;
     bool warm_ok = false;
-#ifndef HSR_MPR_COLD_ONLY
     if (warm && warm[0] > 0) {
         auto rebuild = [&](int id, Sup &p) { p.id = id; p.v1 = support_vertex(G1, id & VID_NONE); p.v2 = support_vertex(G2, (id >> VID_BITS) & VID_NONE); p.v = p.v1 - p.v2; };
         rebuild(warm[0] - 1, p1); rebuild(warm[1] - 1, p2); rebuild(warm[2] - 1, p3);
@@ -813,7 +804,6 @@ template <int W = 1> __device__ bool mpr_penetration(const Geom &G1, const Geom 
         warm_ok = s13 > sc && s32 > sc && s21 > sc;
     }
     if (warm) { warm[0] = warm[1] = warm[2] = 0; }
-#endif
   cold_start:
   if (!warm_ok) {
     p1 = mpr_support<W>(G1, G2, dir); nsup++;
@@ -865,9 +855,7 @@ template <int W = 1> __device__ bool mpr_penetration(const Geom &G1, const Geom 
             // triangle of that face, however the run got there.  Where it does not, libccd measures to the triangle's edge and the answer
             // depends on the triangle: a warm-started run then starts over from scratch, so that it ends where libccd's own search does
             // (as far as single precision follows it).
-#ifndef HSR_MPR_NO_RESTART
             if (!interior && warm_ok) { warm_ok = false; dir = normalized(-p0.v); goto cold_start; }
-#endif
             if (interior) {
                 // the witness is the foot of the perpendicular: depth = |n . v1|, direction = +-n
                 const float dn = dot(dir, p1.v);
@@ -887,12 +875,10 @@ template <int W = 1> __device__ bool mpr_penetration(const Geom &G1, const Geom 
             }
             const float inv = 0.5f * frcp(sum);
             pos = (p0.v1 * b0 + p1.v1 * b1 + p2.v1 * b2 + p3.v1 * b3 + p0.v2 * b0 + p1.v2 * b1 + p2.v2 * b2 + p3.v2 * b3) * inv;
-#ifndef HSR_MPR_COLD_ONLY
             // the portal this run ended on, for the next substep - only vertices carry over (mesh, box)
             auto vertex_ids = [](int id) { return (id & VID_NONE) != VID_NONE && ((id >> VID_BITS) & VID_NONE) != VID_NONE; };
             // (only from a run whose witness was interior: one that ended on a triangle edge would be started over next time anyway)
             if (warm && interior && vertex_ids(p1.id) && vertex_ids(p2.id) && vertex_ids(p3.id)) { warm[0] = p1.id + 1; warm[1] = p2.id + 1; warm[2] = p3.id + 1; }
-#endif
             return true;
         }
         expand_portal(p0, p1, p2, p3, v4);
@@ -971,9 +957,6 @@ __global__ void __launch_bounds__(64) k_cull(DevModel m, DevState s) {
         const int g1 = m.pair_geom1[p], g2 = m.pair_geom2[p];
         const Geom G1 = load_geom(m, s, g1, es), G2 = load_geom(m, s, g2, es);
         bool pass = live && pair_cull(m, G1, G2, g1, g2);
-#ifdef HSR_SKIP_NARROW
-        pass = false;
-#endif
         const unsigned long long bal = __ballot(pass);
         if (bal) {
             const int first = __ffsll((long long)bal) - 1;
@@ -1030,10 +1013,7 @@ __global__ void __launch_bounds__(64) k_narrow(DevModel m, DevState s) {
         if (act) {
             if (fn == FN_PLANE_BOX) collide_plane_box(G1, G2, out);
             else if (fn == FN_PLANE_CONVEX) collide_plane_convex(G1, G2, out);
-#ifndef HSR_SKIP_BOXBOX
             else if (fn == FN_BOX_BOX) collide_box_box(G1, G2, out, poly, lane);
-#endif
-#ifndef HSR_SKIP_MPR
             else {
                 // temporal coherence: the separating direction MPR proved last time is tried first; if it still
                 // separates (two support calls), MPR would again report "no intersection" - identical result
@@ -1057,7 +1037,6 @@ __global__ void __launch_bounds__(64) k_narrow(DevModel m, DevState s) {
                 else atomicAdd(&s.phase_cyc[23], 1ull);
 #endif
             }
-#endif
             s.ncon_pair[(size_t)e * m.npair_pad + p] = out.cnt;
         }
     }

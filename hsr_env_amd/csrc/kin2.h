@@ -76,7 +76,6 @@ struct Kin2 {
     // a loop whose every turn read a joint record and then the coordinate it names.  The joint loop is unrolled over the three joint slots a link can
     // have; a slot no link of the wave uses, and the hinge arm of a slot without a hinge, are skipped wave-uniformly; the slide arm (twelve
     // instructions) and the selects run unconditionally.  Same arithmetic as before, term by term: results are bit-identical.
-#ifndef HSR_KIN_A_OLD
     __device__ __forceinline__ void stageA(const float *kc, int nlink, int c_, float *qposL, float *recL) {
         c = c_; isl = c < nlink;
         K = kc + KIN2_FLOATS * (isl ? c : 0);
@@ -132,45 +131,6 @@ struct Kin2 {
         }
         if (isl) pose_store(recL + 12 * c, R, p);
     }
-#else
-    __device__ __forceinline__ void stageA(const float *kc, int nlink, int c_, float *qposL, float *recL) {
-        c = c_; isl = c < nlink;
-        K = kc + KIN2_FLOATS * (isl ? c : 0);
-        const float4 h0 = kl4(K), h1 = kl4(K + 4);
-        d0 = (int)h0.x; dn = (int)h0.y; free_ = (int)h0.z;
-        const int qadr = (int)h0.w;
-        mass = h1.z; anc = __float_as_uint(h1.w);
-        if (free_) {
-            p = mk3(qposL[qadr], qposL[qadr + 1], qposL[qadr + 2]);
-            q4 q;
-            q.w = qposL[qadr + 3]; q.x = qposL[qadr + 4]; q.y = qposL[qadr + 5]; q.z = qposL[qadr + 6];
-            q = qnormalized(q);                                      // mj_kinematics normalises in place
-            if (isl) { qposL[qadr + 3] = q.w; qposL[qadr + 4] = q.x; qposL[qadr + 5] = q.y; qposL[qadr + 6] = q.z; }
-            R = q2m(q);
-        } else {
-            const float4 lp = kl4(K + 8), m0 = kl4(K + 12), m1 = kl4(K + 16), m2 = kl4(K + 20);
-            p = mk3(lp.x, lp.y, lp.z);
-            R.a[0] = m0.x; R.a[1] = m0.y; R.a[2] = m0.z; R.a[3] = m0.w; R.a[4] = m1.x; R.a[5] = m1.y; R.a[6] = m1.z; R.a[7] = m1.w; R.a[8] = m2.x;
-            for (int j = 0; j < dn; j++) {
-                const float4 j0 = kl4(K + 36 + 8 * j), j1 = kl4(K + 40 + 8 * j);
-                const float q = qposL[(int)j0.x];
-                const v3 ax = mk3(j0.z, j0.w, j1.x);
-                if ((int)j0.y == DOF_SLIDE) p = p + mulmv(R, ax) * q;
-                else {
-                    const v3 jp = mk3(j1.y, j1.z, j1.w);
-                    const v3 anchor = p + mulmv(R, jp);
-                    float sn, cs;
-                    fast_sincos(0.5f * q, &sn, &cs);
-                    q4 qr;
-                    qr.w = cs; qr.x = ax.x * sn; qr.y = ax.y * sn; qr.z = ax.z * sn;
-                    R = mulmm(R, q2m(qr));
-                    p = anchor - mulmv(R, jp);
-                }
-            }
-        }
-        if (isl) pose_store(recL + 12 * c, R, p);
-    }
-#endif
     // B: world pose = T(root) ... T(parent) T(self); the world's own transform is the identity, so lanes with fewer ancestors
     // multiply by it (exactly) instead of leaving the loop
     __device__ __forceinline__ void stageB(int maxdepth, const float *recL, float *poseL) {

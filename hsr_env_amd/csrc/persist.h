@@ -235,11 +235,7 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
   // one run of substeps [sub0, sub1) of a task (the envs of one lane-group set) - or, SOLO, of the single env solo_env in lane group 0
   auto run_task = [&](auto solo_c, const int sub0, const int sub1, const int solo_env) {
     constexpr bool SOLO = decltype(solo_c)::value;
-#ifndef HSR_SOLO_NO_REPLICAS
     constexpr bool REP = SOLO;
-#else
-    constexpr bool REP = false;
-#endif
     (void)solo_env;
     const bool first_run = sub0 == 0, last_run = sub1 >= n_substeps;
     const bool fresh = io.ctrl != nullptr && first_run;       // HSREnv.step begins here: ctrl[:] = action, a fresh done flag (hsr/env.py:116,124)
@@ -506,10 +502,7 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
                 // hulls are scanned along d and the margin is refreshed; MPR runs only when d no longer separates - from the portal of the
                 // previous substep if the pair penetrated then (margin row = -1: rows 0-2 hold its vertex ids).
                 {
-#ifndef HSR_MW
-#define HSR_MW 8
-#endif
-                    constexpr int MW = HSR_MW;
+                    constexpr int MW = 8;          // lanes per convex-pair sub-group (4: -3 %, 16: -1 %)
                     const bool cv = fn == FN_CONVEX;
                     float cdx = 0.f, cdy = 0.f, cdz = 0.f, cmg = 0.f;
                     int cfresh = 0;
@@ -638,11 +631,7 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
         // per-body Hessian accumulators of the solver: the box-box polygon scratch is dead from here to the next substep's collision
         // body b's columns are static tiles counted from nv = NK; with a single block (G = 16) the per-contact assembly is as
         // fast (measured: -DHSR_FB_ALL), so it stays
-#ifdef HSR_FB_ALL
-        const int nfb = EXACT ? m.nfb : 0;
-#else
         const int nfb = (EXACT && G == 32) ? m.nfb : 0;
-#endif
         float *fbK = poly + (size_t)g * 28 * nfb;
         // per-link velocity fields of J v: the rows of the reference-acceleration / residual arrays (both live in the contact lanes' registers
         // since round 3; 2 R floats) - three vectors side by side in the setup, one in the Newton loop.  (Until round 4 the scratch was the
@@ -653,9 +642,7 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
 #define SOLVE_STORE_DIAG dbg_store
 #define SOLVE_COUNT_CAPS 1
 #define PAIR_CNT8(p) (*reinterpret_cast<const unsigned long long *>(pcnt + (p)))
-#ifndef HSR_NO_LANE_TABLES
 #define SOLVE_LANE_TABLES 1
-#endif
 #define SOLVE_LIMITS_FROM_MODEL 1
 #include "solve_body.inc"
 #undef SOLVE_LANE_TABLES

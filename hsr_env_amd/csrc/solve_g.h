@@ -199,9 +199,7 @@ template <int G> __device__ __forceinline__ bool chol_pivots_ok(float invd) {
     return gmax<G>(badp ? 1 : 0) == 0;
 }
 template <int G, int NK = G> __device__ __forceinline__ bool chol_g(float (&row)[G], float &invd, int nv, int ndense, int c) {
-#ifndef HSR_CHOL_MASKS
     asm volatile("" : "+v"(c));          // lane masks formed where they are used, not hoisted out of the caller's loops as spilled SGPR pairs (chol_g_fwd)
-#endif
     invd = 1.f;
     static_for<0, NK>([&](auto jc) {
         constexpr int j = decltype(jc)::value;
@@ -230,11 +228,9 @@ template <int G, int NK = G> __device__ __forceinline__ bool chol_g_fwd(float (&
     invd = 1.f;
     float sacc = b;
     y = 0.f;
-#ifndef HSR_CHOL_MASKS
     // the lane id is laundered per call: the thirteen `c == j` masks are then formed where they are used (one v_cmp each) instead of being hoisted out of
     // the Newton loop as SGPR pairs, spilled into VGPR lanes and read back with two v_readlane per step
     asm volatile("" : "+v"(c));
-#endif
     static_for<0, NK>([&](auto jc) {
         constexpr int j = decltype(jc)::value;
         if (j < nv) {
@@ -250,11 +246,7 @@ template <int G, int NK = G> __device__ __forceinline__ bool chol_g_fwd(float (&
                 constexpr int i = decltype(ic)::value;
                 fmac_bcast<G, i, bc_first<G, i, j + 1>()>(row[i], nl, bl);
             });
-#ifndef HSR_CHOL_MASKS
             fmac_bcast<G, j, true>(sacc, nl, bc_prepare<G>(t));      // sacc -= L[c][j] y_j (a lane c <= j has taken its y already: what lands in its sacc is never read)
-#else
-            fmac_bcast<G, j, true>(sacc, c > j ? nl : 0.f, bc_prepare<G>(t));      // sacc -= L[c][j] y_j
-#endif
         }
     });
     return chol_pivots_ok<G>(invd);
@@ -310,13 +302,7 @@ template <int G, int NK, int ND> __device__ __forceinline__ bool chol_sparse_fwd
         constexpr int t = decltype(tc)::value;
         float mine = row[ND + t];
         static_for<1, NB>([&](auto bc_) { constexpr int bb = decltype(bc_)::value; mine = fb == bb ? row[ND + 6 * bb + t] : mine; });
-#ifdef HSR_SPARSE_READLANE
-        // (the pivot of the lane's own body by NB readlane broadcasts and a select instead of one ds_bpermute with a per-lane source: measured, no faster)
-        float ajj = gbcast_after_asm<G, ND + t>(row[ND + t]);
-        static_for<1, NB>([&](auto bc_) { constexpr int bb = decltype(bc_)::value; const float a_ = gbcast_after_asm<G, ND + 6 * bb + t>(row[ND + 6 * bb + t]); ajj = fb == bb ? a_ : ajj; });
-#else
         const float ajj = __int_as_float(__builtin_amdgcn_ds_bpermute(pl0 + 4 * t, __float_as_int(mine)));
-#endif
         const float inv = __builtin_amdgcn_rsqf(ajj);
         const float l = mine * inv;
         const float tz = sacc * inv;
@@ -331,13 +317,7 @@ template <int G, int NK, int ND> __device__ __forceinline__ bool chol_sparse_fwd
                 static_for<t + 1, 6>([&](auto sc) { constexpr int k = ND + 6 * bb + decltype(sc)::value; fmac_bcast<G, k, (bb == 0 && k == ND + t + 1) || k == 16>(row[k], nlb[bb], bl); });
             });
         }
-#ifdef HSR_SPARSE_READLANE
-        float zt = gbcast<G, ND + t>(tz);
-        static_for<1, NB>([&](auto bc_) { constexpr int bb = decltype(bc_)::value; const float z_ = gbcast<G, ND + 6 * bb + t>(tz); zt = fb == bb ? z_ : zt; });
-        (void)pl0;
-#else
         const float zt = __int_as_float(__builtin_amdgcn_ds_bpermute(pl0 + 4 * t, __float_as_int(tz)));
-#endif
         sacc = __builtin_fmaf(-l, zt, sacc);                             // sacc -= L[c][j] y_j, j = this lane's body's dof t
     });
     return chol_pivots_ok<G>(invd);
@@ -435,9 +415,7 @@ struct HessAcc32 {
 // matrix M and M + h D of a robot followed by free bodies with principal-axis inertia: ND pivot steps with updates of the first ND
 // rows only, and every tail lane takes the reciprocal root of its own diagonal entry (diag: lane c's M[c][c]; 1 for the padding lanes).
 template <int G, int NK, int ND> __device__ __forceinline__ bool chol_g_tail(float (&row)[G], float &invd, float diag, int c) {
-#ifndef HSR_CHOL_MASKS
     asm volatile("" : "+v"(c));          // lane masks formed where they are used, not hoisted out of the caller's loops as spilled SGPR pairs (chol_g_fwd)
-#endif
     invd = 1.f;
     static_for<0, ND>([&](auto jc) {
         constexpr int j = decltype(jc)::value;

@@ -34,9 +34,7 @@ template <int G> struct MfLayout {
 
 // tile-free triangular solves: lane c holds lo[k] = L[c][k] (k < c, else 0) and invd = 1 / L[c][c]
 template <int G, int NK = G> __device__ __forceinline__ float chol_solve_mf(const float (&row)[G], float invd, float b, int nv, int c) {
-#ifndef HSR_CHOL_MASKS
     asm volatile("" : "+v"(c));          // lane masks formed where they are used, not hoisted out of the caller's loops as spilled SGPR pairs (chol_g_fwd)
-#endif
     float nlo[G];                                                // minus the strictly lower part of row c of L, 0 elsewhere
 #pragma unroll
     for (int k = 0; k < NK; k++) nlo[k] = (k < c) ? -row[k] : 0.f;
@@ -71,9 +69,7 @@ template <int G, int NK = G> __device__ __forceinline__ float chol_solve_mf(cons
 
 // back substitution alone (the forward half was done by chol_g_fwd): lane c holds y_c, the strictly lower part of row c of L and invd
 template <int G, int NK = G> __device__ __forceinline__ float chol_back_mf(const float (&row)[G], float invd, float y, int nv, int c) {
-#ifndef HSR_CHOL_MASKS
     asm volatile("" : "+v"(c));          // lane masks formed where they are used, not hoisted out of the caller's loops as spilled SGPR pairs (chol_g_fwd)
-#endif
     float nlo[G];
 #pragma unroll
     for (int k = 0; k < NK; k++) nlo[k] = (k < c) ? -row[k] : 0.f;
@@ -96,9 +92,7 @@ template <int G, int NK = G> __device__ __forceinline__ float chol_back_mf(const
 
 // ... and the two substitutions with such a factor (chol_g_tail): ND dependent steps each; a tail lane solves its own equation
 template <int G, int NK, int ND> __device__ __forceinline__ float chol_solve_tail(const float (&row)[G], float invd, float b, int c) {
-#ifndef HSR_CHOL_MASKS
     asm volatile("" : "+v"(c));          // lane masks formed where they are used, not hoisted out of the caller's loops as spilled SGPR pairs (chol_g_fwd)
-#endif
     float nlo[ND > 0 ? ND : 1];
 #pragma unroll
     for (int k = 0; k < ND; k++) nlo[k] = (k < c && c < ND) ? -row[k] : 0.f;

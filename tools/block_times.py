@@ -58,6 +58,11 @@ if os.environ.get('HSR_CPLSTAT'):      # timing build with -DHSR_CPLSTAT: counte
     for nm, idx in (('all', o), ('slowest 20', o[-20:]), ('median 20', o[nb // 2 - 10: nb // 2 + 10])):
         tot = max((c0[idx] + c1[idx] + c2[idx]).sum(), 1)
         print('coupling of the contact list (lane 0 env), %s: no robot <-> body contact %.2f, one body coupled to the robot and no body <-> body %.2f, more %.2f' % (nm, c0[idx].sum() / tot, c1[idx].sum() / tot, c2[idx].sum() / tot))
+if os.environ.get('HSR_ACTSTAT'):      # timing build with -DHSR_ACTSTAT: counter 3 = Newton trips of the wave by the number of envs still iterating
+    c1, c2, c3 = a[:, 7] & 0x1fffff, (a[:, 7] >> 21) & 0x1fffff, (a[:, 7] >> 42) & 0x1fffff
+    for nm, idx in (('all', o), ('slowest 20', o[-20:]), ('median 20', o[nb // 2 - 10: nb // 2 + 10])):
+        tot = max((c1[idx] + c2[idx] + c3[idx]).sum(), 1)
+        print('Newton trips of a wave by envs still iterating, %s: one %.2f, two %.2f, three or four %.2f (trips / substep %.2f)' % (nm, c1[idx].sum() / tot, c2[idx].sum() / tot, c3[idx].sum() / tot, tot / len(idx) / 300))
 print('nefc sum / substep: mean %.2f, slowest 10 %s' % (a[:, 7].mean() / 300, (a[o[-10:], 7] / 300).round(2)))
 print('corr(life, newton) %.3f  corr(life, items) %.3f corr(life, nefc) %.3f' % (np.corrcoef(life, a[:, 4])[0, 1], np.corrcoef(life, a[:, 6])[0, 1], np.corrcoef(life, a[:, 7])[0, 1]))
 A = np.stack([np.ones(nb), a[:, 4], a[:, 6], a[:, 7]], 1).astype(np.float64)
