@@ -784,7 +784,7 @@ __device__ __forceinline__ bool reach_tol(const Sup &p1, const Sup &p2, const Su
 // The same six material points, placed with the present poses, are a portal again whenever the origin ray still passes through their
 // triangle (checked; else the search starts from scratch): the refinement then confirms the face it ended on last time with one or
 // two support calls instead of rediscovering it with eight.
-template <int W = 1> __device__ bool mpr_penetration(const Geom &G1, const Geom &G2, float tol, int maxit, float &depth, v3 &dirout, v3 &pos, v3 &sep, int &nsup, int *warm = nullptr) {
+template <int W = 1> __device__ __forceinline__ bool mpr_penetration(const Geom &G1, const Geom &G2, float tol, int maxit, float &depth, v3 &dirout, v3 &pos, v3 &sep, int &nsup, int *warm = nullptr) {
     const float eps = HSR_EPS;
     Sup p0, p1, p2, p3, v4;
     p0.v1 = G1.pos; p0.v2 = G2.pos; p0.v = p0.v1 - p0.v2; p0.id = 0;

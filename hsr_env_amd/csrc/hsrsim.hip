@@ -277,13 +277,39 @@ __global__ void k_build_tables(DevModel m, DevState s) {
 // (cfg_consts.h, generated from the committed blobs; chosen only when the loaded model matches the generated row value for value -
 // HSR_NO_CONST=1 never chooses them); any other model runs a generic instance (lanes per env, bound on nv).
 typedef void (*persist_fn)(const DevModel *, DevState, int, int, float, int, StepIO);
+static void quat2mat_h(const double *q, float *mt);
+// row + 1 of the constant instance whose compile-time tree tables (cfg_consts.h: Kin3_<cfg>) equal the loaded model's, 0 if none: the order of
+// the entries is the one tools/gen_cfg_consts.py writes
+static int kin3_matching_row(const hsr_model *m) {
+    const int nv = m->sizes[1], nlink = m->sizes[3];
+    std::vector<int> iv = {nlink, nv};
+    for (const char *n : {"link_parent", "link_free", "link_dofadr", "link_dofnum", "link_qposadr", "dof_type", "dof_qposadr", "dof_link"}) {
+        size_t cnt = 0; const int *p = m->i32(n, &cnt);
+        if (!p) return 0;
+        iv.insert(iv.end(), p, p + cnt);
+    }
+    std::vector<float> fv;
+    auto addf = [&](const char *n) { size_t cnt = 0; const double *p = m->f64(n, &cnt); if (!p) return false; for (size_t i = 0; i < cnt; i++) fv.push_back((float)p[i]); return true; };
+    if (!addf("link_pos")) return 0;
+    { size_t cnt = 0; const double *q = m->f64("link_quat", &cnt); if (!q) return 0; for (size_t i = 0; i < cnt / 4; i++) { float mt[9]; quat2mat_h(q + 4 * i, mt); fv.insert(fv.end(), mt, mt + 9); } }
+    if (!addf("link_com") || !addf("link_inertia") || !addf("link_mass") || !addf("dof_axis") || !addf("dof_pos")) return 0;
+    for (size_t r = 0; r < sizeof kKin3Checks / sizeof kKin3Checks[0]; r++) {
+        const Kin3Check &k = kKin3Checks[r];
+        if (k.i && k.ni == (int)iv.size() && k.nf == (int)fv.size() && memcmp(k.i, iv.data(), iv.size() * sizeof(int)) == 0 && memcmp(k.f, fv.data(), fv.size() * sizeof(float)) == 0) return (int)r + 1;
+    }
+    return 0;
+}
 static int cfg_const_row(const DevModel &d) {
     const char *nc = getenv("HSR_NO_CONST");
     if (nc && strcmp(nc, "0") != 0) return -1;
     int iv[sizeof kCfgConsts[0].i / sizeof(int)]; float fv[sizeof kCfgConsts[0].f / sizeof(float)];
     cfg_const_values(d, iv, fv);
     for (size_t r = 0; r < sizeof kCfgConsts / sizeof kCfgConsts[0]; r++)
-        if (memcmp(iv, kCfgConsts[r].i, sizeof iv) == 0 && memcmp(fv, kCfgConsts[r].f, sizeof fv) == 0) return (int)r;
+        if (memcmp(iv, kCfgConsts[r].i, sizeof iv) == 0 && memcmp(fv, kCfgConsts[r].f, sizeof fv) == 0) {
+            // an instance compiled with its kinematic tree (kin3.h) serves only a model whose tree is that one, value for value (hsr_batch_create: kin3_match)
+            if (kKin3Checks[r].i && d.kin3_match != (int)r + 1) return -1;
+            return (int)r;
+        }
     return -1;
 }
 enum { QUEUE_ROUNDS = 64 };
@@ -712,6 +738,7 @@ static int batch_init(hsr_batch *b, const hsr_model *m, int n_envs) {
         }
     }
     {
+        d.kin3_match = kin3_matching_row(m);
         {   // (before an instance is chosen: the constant instances are matched on nfb too)
             // trailing free bodies: link l owns exactly the dofs [nv - 6 (k + 1), nv - 6 k), lin then ang
             const int *dn = m->i32("link_dofnum"), *lf = m->i32("link_free"), *da = m->i32("link_dofadr"), *dt = m->i32("dof_type"), *dl = m->i32("dof_link");
@@ -858,7 +885,12 @@ extern "C" int hsr_batch_set_persistent(hsr_batch *b, int on) {
     b->persist = want;
     return b->persist ? 1 : 0;
 }
-extern "C" int hsr_batch_is_persistent(const hsr_batch *b) { NULLCHK(b); return b->persist ? 1 : 0; }
+extern "C" int hsr_batch_is_persistent(const hsr_batch *b) {
+    NULLCHK(b);
+    if (!b->persist) return 0;
+    const int row = cfg_const_row(b->dm);
+    return 1 | (row >= 0 ? 2 : 0) | ((row >= 0 && kKin3Checks[row].i) ? 4 : 0);
+}
 extern "C" int hsr_batch_set_debug(hsr_batch *b, int on) { if (!b) return fail(HSR_EINVAL, "null batch"); b->debug_store = (on & 1) != 0; b->test_hooks = on & (6 | 16 | 32 | 64 | 128); return HSR_OK; }
 extern "C" int hsr_batch_set_schedule(hsr_batch *b, int on) { NULLCHK(b); b->schedule = on != 0; return HSR_OK; }
 extern "C" int hsr_batch_set_mpr_warm(hsr_batch *b, int on) {

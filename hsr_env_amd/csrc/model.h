@@ -36,6 +36,7 @@ struct DevModel {
     int nfb;                          // free bodies whose six dofs (3 lin, 3 ang) form the tail of the dof vector, one after the other: their
                                       // contacts with the world are assembled per body in the Newton Hessian (solve_body.inc); 0 = none / not applicable
     const float *act_gear, *act_kp, *act_ctrlrange, *act_forcerange;
+    int kin3_match;                   // host side: row + 1 of the constant instance (cfg_consts.h) whose compile-time tree tables equal this model's, 0 = none
 };
 
 // env-step inputs / outputs of the caller (hsr_batch_step_dev), env-major as the C-ABI hands them over: the persistent kernel reads ctrl

@@ -20,6 +20,7 @@
 #pragma once
 #include "collide.h"
 #include "kin2.h"
+#include "kin3.h"
 #include "solve_mf.h"
 
 template <int G> struct PersistLayout {
@@ -286,7 +287,16 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
         // ---------------- K: kinematics + RNE recursion (kin2.h): lane = link / dof, only the parent-dependent part per tree level
         qposL[c] = qpos_c; qvelL[c] = qvel_c;
         wave_sync();
-        {
+        // KIN3: the instance knows its kinematic tree at compile time (kin3.h): poses, velocities, inertia rows and bias force in one straight-line pass
+        typedef typename Kin3Of<MT>::type KD;
+        constexpr bool KIN3 = KD::ok && EXACT;
+        if constexpr (KIN3) {
+#ifndef HSR_K3_NORUN
+            kin3_run<KD, G, NK>(c, m.gravz, qposL, qvelL, poseL, recL, kAng);
+#endif
+            wave_sync();
+            PHASE_K(26);
+        } else {
             float *dwL = qvelL + G;                              // the geom placements are written after the kinematics
             Kin2 kin;
             kin.stageA(lds + L.oKin, m.nlink, c, qposL, recL);

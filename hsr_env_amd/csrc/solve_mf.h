@@ -10,6 +10,7 @@
 // scalars): 8 single-wave workgroups fit a CU, i.e. 2 waves per SIMD instead of 1 with the stored-Jacobian kernel.
 #pragma once
 #include "solve_g.h"
+#include "kin3.h"
 
 // contact record in LDS: 11 float4 (16-B aligned), grouped so that each consumer needs few ds_read_b128:
 //   q0 pos.xyz L1 | q1 n.xyz L2 | q2 t1.xyz ADR | q3 t2.xyz DIM | q4 MU F0 F2 F3 | q5 ZONE DM K3 B | q6 fw.xyz KD | q7 tw.xyz - |
@@ -205,6 +206,7 @@ __global__ void __launch_bounds__(64, 2) k_solve_mf(DevModel m, DevState s, int 
         }
     }
     constexpr int NDK = -1;                // ... and the run-time ndense
+    constexpr bool KIN3 = false;           // (kin3.h, compile-time tree: persistent kernel only)
     constexpr bool REP = false;            // (solo-server replicas: persistent kernel only)
     using MT = DevModel;                  // (the chain kernel reads every model field at run time)
     constexpr bool hook_jv_per_contact = false, hook_majorant = false, hook_dense_chol = false, EXACT_CT = false;

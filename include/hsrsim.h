@@ -121,7 +121,8 @@ int hsr_batch_set_graph(hsr_batch *b, int on);
 /* whole env-step in ONE persistent kernel (default on when the model fits: nv <= 32, LDS budget); returns the
  * resulting setting.  With it on, hsr_batch_last_timing() reports the persistent kernel in slot 2 (slots 0,1 = 0). */
 int hsr_batch_set_persistent(hsr_batch *b, int on);
-int hsr_batch_is_persistent(const hsr_batch *b);
+int hsr_batch_is_persistent(const hsr_batch *b);                  /* 0 = per-substep chain; else bit 0 set, bit 1: the kernel instance carries the model's scalars as
+                                                                    * compile-time constants, bit 2: and its kinematic tree (straight-line kinematics / inertia) */
 /* introspection after hsr_batch_step*: with it on, the persistent kernel also stores what hsr_batch_forward stores - the
  * per-pair contact counts (HSR_F_CONTACT), HSR_F_NCON / NEFC / NITER and HSR_F_QACC of every env's LAST substep (default off:
  * the fields then describe the last hsr_batch_forward).  Parity tests of the hot path's own narrowphase use it.

@@ -17,7 +17,10 @@ HIPCC = "/opt/rocm/bin/hipcc"
 def assembly(tmp_path_factory):
     """The device assembly of every kernel instance, compiled once for the module (no GPU needed)."""
     out = tmp_path_factory.mktemp("isa") / "hsrsim.s"
-    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-S", "--cuda-device-only",
+    import sys
+    sys.path.insert(0, str(ROOT))
+    from hsr_env_amd.build import CODEGEN_FLAGS          # the product build's flags
+    subprocess.check_call([HIPCC, *CODEGEN_FLAGS, "-S", "--cuda-device-only",
                            "-Wno-unused-result", "-Wno-unused-value", "-o", str(out), str(ROOT / "hsr_env_amd" / "csrc" / "hsrsim.hip")],
                           stderr=subprocess.DEVNULL)
     return out.read_text()

@@ -5,7 +5,9 @@ import subprocess, sys
 from concurrent.futures import ThreadPoolExecutor
 from pathlib import Path
 HERE = Path(__file__).resolve().parent.parent / "hsr_env_amd"
-BASE = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-shared", "-fPIC", "-w"]
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+from hsr_env_amd.build import CODEGEN_FLAGS  # noqa: E402
+BASE = ["/opt/rocm/bin/hipcc", *CODEGEN_FLAGS, "-shared", "-fPIC", "-w"]
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
 cfg3 = "--cfg3" in sys.argv
 kinds = "ptl"
