@@ -1,5 +1,5 @@
 /*
- * hsr_oracle.c - CPU fp64 restatement of one MuJoCo substep (mj_step) for the HSR scene.
+ * hsr_oracle.c - CPU fp64 (HO_REAL = double; float on request) restatement of one MuJoCo substep (mj_step) for the HSR scene.
  *
  * TEST INFRASTRUCTURE ONLY.  Nothing under hsr_env_amd/ (the product) may import, link or call
  * this file; it is used by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
@@ -29,6 +29,13 @@
 #include <stdlib.h>
 #include <string.h>
 
+/* the arithmetic type: double (the oracle); `make libhsr_oracle_f32.so` builds the same restatement with -DHO_REAL=float for the tests that ask
+ * whether a difference between the fp32 kernels and this oracle is PRECISION (tests/test_gpu_hotpath.py: the pinch regime): test infrastructure only */
+#ifndef HO_REAL
+#define HO_REAL double
+#endif
+typedef HO_REAL real;
+
 #define NV_MAX 32
 #define NCON_MAX 128
 #define NEFC_MAX 512
@@ -46,104 +53,105 @@ enum { FN_PLANE_BOX = 0, FN_PLANE_CONVEX = 1, FN_BOX_BOX = 2, FN_CONVEX = 3 };
 
 typedef struct {
     void *blob;
-    const int *sizes; const double *opt;
+    const int *sizes; const real *opt;
     int nq, nv, nu, nlink, nbody, ngeom, npair, nmeshvert, nconmax, njmax;
-    const double *qpos0;
-    const int *link_parent; const double *link_pos, *link_quat;
+    const real *qpos0;
+    const int *link_parent; const real *link_pos, *link_quat;
     const int *link_dofadr, *link_dofnum, *link_qposadr, *link_free;
-    const double *link_mass, *link_com, *link_inertia;
-    const int *dof_link, *dof_type; const double *dof_axis, *dof_pos; const int *dof_parent;
-    const double *dof_damping; const int *dof_qposadr; const double *dof_invweight0;
-    const int *dof_limited; const double *dof_range, *dof_solref, *dof_solimp;
-    const int *body_link; const double *body_pos, *body_quat; const int *body_mocap;
-    const int *geom_type, *geom_link, *geom_body; const double *geom_pos, *geom_quat, *geom_size,
+    const real *link_mass, *link_com, *link_inertia;
+    const int *dof_link, *dof_type; const real *dof_axis, *dof_pos; const int *dof_parent;
+    const real *dof_damping; const int *dof_qposadr; const real *dof_invweight0;
+    const int *dof_limited; const real *dof_range, *dof_solref, *dof_solimp;
+    const int *body_link; const real *body_pos, *body_quat; const int *body_mocap;
+    const int *geom_type, *geom_link, *geom_body; const real *geom_pos, *geom_quat, *geom_size,
         *geom_rbound; const int *geom_condim, *geom_meshadr, *geom_meshnum;
-    const double *geom_invweight, *mesh_vert;
+    const real *geom_invweight, *mesh_vert;
     const int *pair_geom1, *pair_geom2, *pair_fn, *pair_condim, *pair_slot;
-    const double *pair_friction, *pair_solref, *pair_solimp;
-    const int *act_dof; const double *act_gear, *act_kp, *act_ctrlrange, *act_forcerange;
-    double *geom_lmat;  /* [ngeom*9] geom rotation in link frame */
+    const real *pair_friction, *pair_solref, *pair_solimp;
+    const int *act_dof; const real *act_gear, *act_kp, *act_ctrlrange, *act_forcerange;
+    real *geom_lmat;  /* [ngeom*9] geom rotation in link frame */
+    void *conv[64]; int nconv;   /* converted tables of a float build */
 } ho_model;
 
 typedef struct {
-    double pos[3], frame[9], dist;
+    real pos[3], frame[9], dist;
     int geom1, geom2, link1, link2, dim, pair;
-    double friction[5], solref[2], solimp[5], mu;
+    real friction[5], solref[2], solimp[5], mu;
     int efc_address;
 } ho_contact;
 
 typedef struct {
     /* state */
-    double *qpos, *qvel, *ctrl, *qacc_warmstart, mocap_pos[3], time;
+    real *qpos, *qvel, *ctrl, *qacc_warmstart, mocap_pos[3], time;
     /* kinematics */
-    double *xpos, *xquat, *xmat, *dof_ang, *dof_lin, *dof_anchor;
-    double *link_w, *link_vo, *link_alpha, *link_ao;
-    double *gpos, *gmat;
+    real *xpos, *xquat, *xmat, *dof_ang, *dof_lin, *dof_anchor;
+    real *link_w, *link_vo, *link_alpha, *link_ao;
+    real *gpos, *gmat;
     /* dynamics */
-    double *M, *L, *qfrc_bias, *qfrc_passive, *qfrc_actuator, *qfrc_smooth, *qacc_smooth;
+    real *M, *L, *qfrc_bias, *qfrc_passive, *qfrc_actuator, *qfrc_smooth, *qacc_smooth;
     /* contacts / constraints */
     int ncon, nefc, nlimit_active;
     ho_contact *contact;
-    double *efc_J, *efc_pos, *efc_D, *efc_R, *efc_aref, *efc_force, *efc_vel, *efc_B, *efc_K;
+    real *efc_J, *efc_pos, *efc_D, *efc_R, *efc_aref, *efc_force, *efc_vel, *efc_B, *efc_K;
     int *efc_type; /* 0 limit, 1 contact-first-row, 2 contact-other-row */
-    double *qacc, *qfrc_constraint;
+    real *qacc, *qfrc_constraint;
     int solver_niter, bad;
-    double solver_cost;
+    real solver_cost;
     /* introspection for tests/test_oracle_optimality.py: accepted cost after the warm-start choice ([0]) and after every Newton iteration, the largest
      * number of line-search evaluations one iteration needed, and whether a step that would have raised the cost was refused */
-    double solver_trace[104];
+    real solver_trace[104];
     int solver_ntrace, solver_ls_max, solver_refused;
     int euler_rhs_macc;   /* test option (ho_set_euler_rhs): mj_Euler's damped solve takes M qacc as its right-hand side, as the HIP path does */
 } ho_data;
 
 /* ------------------------------------------------------------------ tiny vector helpers */
-static inline double dot3(const double *a, const double *b) { return a[0]*b[0] + a[1]*b[1] + a[2]*b[2]; }
-static inline void cross3(double *r, const double *a, const double *b) {
-    double x = a[1]*b[2] - a[2]*b[1], y = a[2]*b[0] - a[0]*b[2], z = a[0]*b[1] - a[1]*b[0];
+static inline real dot3(const real *a, const real *b) { return a[0]*b[0] + a[1]*b[1] + a[2]*b[2]; }
+static inline void cross3(real *r, const real *a, const real *b) {
+    real x = a[1]*b[2] - a[2]*b[1], y = a[2]*b[0] - a[0]*b[2], z = a[0]*b[1] - a[1]*b[0];
     r[0] = x; r[1] = y; r[2] = z;
 }
-static inline void sub3(double *r, const double *a, const double *b) { r[0]=a[0]-b[0]; r[1]=a[1]-b[1]; r[2]=a[2]-b[2]; }
-static inline void add3(double *r, const double *a, const double *b) { r[0]=a[0]+b[0]; r[1]=a[1]+b[1]; r[2]=a[2]+b[2]; }
-static inline void copy3(double *r, const double *a) { r[0]=a[0]; r[1]=a[1]; r[2]=a[2]; }
-static inline void scl3(double *r, const double *a, double s) { r[0]=a[0]*s; r[1]=a[1]*s; r[2]=a[2]*s; }
-static inline void addscl3(double *r, const double *a, double s) { r[0]+=a[0]*s; r[1]+=a[1]*s; r[2]+=a[2]*s; }
-static inline double norm3(const double *a) { return sqrt(dot3(a, a)); }
-static inline double normalize3(double *a) {
-    double n = norm3(a);
+static inline void sub3(real *r, const real *a, const real *b) { r[0]=a[0]-b[0]; r[1]=a[1]-b[1]; r[2]=a[2]-b[2]; }
+static inline void add3(real *r, const real *a, const real *b) { r[0]=a[0]+b[0]; r[1]=a[1]+b[1]; r[2]=a[2]+b[2]; }
+static inline void copy3(real *r, const real *a) { r[0]=a[0]; r[1]=a[1]; r[2]=a[2]; }
+static inline void scl3(real *r, const real *a, real s) { r[0]=a[0]*s; r[1]=a[1]*s; r[2]=a[2]*s; }
+static inline void addscl3(real *r, const real *a, real s) { r[0]+=a[0]*s; r[1]+=a[1]*s; r[2]+=a[2]*s; }
+static inline real norm3(const real *a) { return sqrt(dot3(a, a)); }
+static inline real normalize3(real *a) {
+    real n = norm3(a);
     if (n < MINVAL) { a[0] = 1; a[1] = 0; a[2] = 0; return 0; }
     a[0] /= n; a[1] /= n; a[2] /= n; return n;
 }
 /* r = M v (row-major 3x3) */
-static inline void mulmv3(double *r, const double *m, const double *v) {
-    double x = m[0]*v[0]+m[1]*v[1]+m[2]*v[2], y = m[3]*v[0]+m[4]*v[1]+m[5]*v[2], z = m[6]*v[0]+m[7]*v[1]+m[8]*v[2];
+static inline void mulmv3(real *r, const real *m, const real *v) {
+    real x = m[0]*v[0]+m[1]*v[1]+m[2]*v[2], y = m[3]*v[0]+m[4]*v[1]+m[5]*v[2], z = m[6]*v[0]+m[7]*v[1]+m[8]*v[2];
     r[0]=x; r[1]=y; r[2]=z;
 }
 /* r = M^T v */
-static inline void mulmtv3(double *r, const double *m, const double *v) {
-    double x = m[0]*v[0]+m[3]*v[1]+m[6]*v[2], y = m[1]*v[0]+m[4]*v[1]+m[7]*v[2], z = m[2]*v[0]+m[5]*v[1]+m[8]*v[2];
+static inline void mulmtv3(real *r, const real *m, const real *v) {
+    real x = m[0]*v[0]+m[3]*v[1]+m[6]*v[2], y = m[1]*v[0]+m[4]*v[1]+m[7]*v[2], z = m[2]*v[0]+m[5]*v[1]+m[8]*v[2];
     r[0]=x; r[1]=y; r[2]=z;
 }
-static inline void mulmm3(double *r, const double *a, const double *b) {
-    double t[9];
+static inline void mulmm3(real *r, const real *a, const real *b) {
+    real t[9];
     for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++)
         t[3*i+j] = a[3*i]*b[j] + a[3*i+1]*b[3+j] + a[3*i+2]*b[6+j];
     memcpy(r, t, sizeof t);
 }
-static inline void quat2mat(double *m, const double *q) {
-    double w=q[0], x=q[1], y=q[2], z=q[3];
+static inline void quat2mat(real *m, const real *q) {
+    real w=q[0], x=q[1], y=q[2], z=q[3];
     m[0]=1-2*(y*y+z*z); m[1]=2*(x*y-w*z); m[2]=2*(x*z+w*y);
     m[3]=2*(x*y+w*z); m[4]=1-2*(x*x+z*z); m[5]=2*(y*z-w*x);
     m[6]=2*(x*z-w*y); m[7]=2*(y*z+w*x); m[8]=1-2*(x*x+y*y);
 }
-static inline void quatmul(double *r, const double *a, const double *b) {
-    double w = a[0]*b[0]-a[1]*b[1]-a[2]*b[2]-a[3]*b[3];
-    double x = a[0]*b[1]+a[1]*b[0]+a[2]*b[3]-a[3]*b[2];
-    double y = a[0]*b[2]-a[1]*b[3]+a[2]*b[0]+a[3]*b[1];
-    double z = a[0]*b[3]+a[1]*b[2]-a[2]*b[1]+a[3]*b[0];
+static inline void quatmul(real *r, const real *a, const real *b) {
+    real w = a[0]*b[0]-a[1]*b[1]-a[2]*b[2]-a[3]*b[3];
+    real x = a[0]*b[1]+a[1]*b[0]+a[2]*b[3]-a[3]*b[2];
+    real y = a[0]*b[2]-a[1]*b[3]+a[2]*b[0]+a[3]*b[1];
+    real z = a[0]*b[3]+a[1]*b[2]-a[2]*b[1]+a[3]*b[0];
     r[0]=w; r[1]=x; r[2]=y; r[3]=z;
 }
-static inline void quatnorm(double *q) {
-    double n = sqrt(q[0]*q[0]+q[1]*q[1]+q[2]*q[2]+q[3]*q[3]);
+static inline void quatnorm(real *q) {
+    real n = sqrt(q[0]*q[0]+q[1]*q[1]+q[2]*q[2]+q[3]*q[3]);
     if (n < MINVAL) { q[0]=1; q[1]=q[2]=q[3]=0; return; }
     q[0]/=n; q[1]/=n; q[2]/=n; q[3]/=n;
 }
@@ -151,6 +159,22 @@ static inline void quatnorm(double *q) {
 /* ------------------------------------------------------------------ blob loader */
 typedef struct { char name[32]; uint32_t dtype, ndim, shape[4]; uint64_t off, nbytes; } blob_entry;
 
+static const void *blob_find(const uint8_t *raw, const char *name, const uint8_t *data, uint32_t n);
+/* an f64 table of the blob as reals: the blob's own memory for real = double, a converted copy (owned by the model: m->conv) otherwise */
+static const void *blob_reals(ho_model *m, const uint8_t *raw, const char *name, const uint8_t *data, uint32_t n) {
+    const blob_entry *e = (const blob_entry *)(raw + 16);
+    for (uint32_t i = 0; i < n; i++)
+        if (strncmp(e[i].name, name, 32) == 0) {
+            const double *src = (const double *)(data + e[i].off);          /* (spelled out: this one IS the blob's f64) */
+            if (sizeof(real) == sizeof(double)) return src;
+            size_t cnt = (size_t)(e[i].nbytes / 8);
+            real *dst = (real *)malloc(sizeof(real) * (cnt ? cnt : 1));
+            for (size_t k = 0; k < cnt; k++) dst[k] = (real)src[k];
+            if (m->nconv < 64) m->conv[m->nconv++] = dst;
+            return dst;
+        }
+    return blob_find(raw, name, data, n);
+}
 static const void *blob_find(const uint8_t *raw, const char *name, const uint8_t *data, uint32_t n) {
     const blob_entry *e = (const blob_entry *)(raw + 16);
     for (uint32_t i = 0; i < n; i++)
@@ -169,18 +193,21 @@ ho_model *ho_model_load(const void *blob, size_t len) {
     const uint8_t *p = raw + 16 + (size_t)n * sizeof(blob_entry);
     uint64_t jl = *(const uint64_t *)p;
     const uint8_t *data = p + 8 + jl;
+    /* int tables point into the blob; real tables too when real is the blob's f64, else they are converted once (FD) */
 #define F(field) m->field = blob_find(raw, #field, data, n)
-    F(sizes); F(opt); F(qpos0);
-    F(link_parent); F(link_pos); F(link_quat); F(link_dofadr); F(link_dofnum); F(link_qposadr);
-    F(link_free); F(link_mass); F(link_com); F(link_inertia);
-    F(dof_link); F(dof_type); F(dof_axis); F(dof_pos); F(dof_parent); F(dof_damping); F(dof_qposadr);
-    F(dof_invweight0); F(dof_limited); F(dof_range); F(dof_solref); F(dof_solimp);
-    F(body_link); F(body_pos); F(body_quat); F(body_mocap);
-    F(geom_type); F(geom_link); F(geom_body); F(geom_pos); F(geom_quat); F(geom_size); F(geom_rbound);
-    F(geom_condim); F(geom_meshadr); F(geom_meshnum); F(geom_invweight); F(mesh_vert);
-    F(pair_geom1); F(pair_geom2); F(pair_fn); F(pair_condim); F(pair_slot); F(pair_friction);
-    F(pair_solref); F(pair_solimp);
-    F(act_dof); F(act_gear); F(act_kp); F(act_ctrlrange); F(act_forcerange);
+#define FD(field) m->field = (const real *)blob_reals(m, raw, #field, data, n)
+    F(sizes); FD(opt); FD(qpos0);
+    F(link_parent); FD(link_pos); FD(link_quat); F(link_dofadr); F(link_dofnum); F(link_qposadr);
+    F(link_free); FD(link_mass); FD(link_com); FD(link_inertia);
+    F(dof_link); F(dof_type); FD(dof_axis); FD(dof_pos); F(dof_parent); FD(dof_damping); F(dof_qposadr);
+    FD(dof_invweight0); F(dof_limited); FD(dof_range); FD(dof_solref); FD(dof_solimp);
+    F(body_link); FD(body_pos); FD(body_quat); F(body_mocap);
+    F(geom_type); F(geom_link); F(geom_body); FD(geom_pos); FD(geom_quat); FD(geom_size); FD(geom_rbound);
+    F(geom_condim); F(geom_meshadr); F(geom_meshnum); FD(geom_invweight); FD(mesh_vert);
+    F(pair_geom1); F(pair_geom2); F(pair_fn); F(pair_condim); F(pair_slot); FD(pair_friction);
+    FD(pair_solref); FD(pair_solimp);
+    F(act_dof); FD(act_gear); FD(act_kp); FD(act_ctrlrange); FD(act_forcerange);
+#undef FD
 #undef F
     m->nq = m->sizes[SZ_NQ]; m->nv = m->sizes[SZ_NV]; m->nu = m->sizes[SZ_NU];
     m->nlink = m->sizes[SZ_NLINK]; m->nbody = m->sizes[SZ_NBODY]; m->ngeom = m->sizes[SZ_NGEOM];
@@ -188,14 +215,15 @@ ho_model *ho_model_load(const void *blob, size_t len) {
     m->nconmax = m->sizes[SZ_NCONMAX] < NCON_MAX ? m->sizes[SZ_NCONMAX] : NCON_MAX;
     m->njmax = m->sizes[SZ_NJMAX] < NEFC_MAX ? m->sizes[SZ_NJMAX] : NEFC_MAX;
     if (m->nv > NV_MAX) { free(m->blob); free(m); return NULL; }
-    m->geom_lmat = (double *)malloc(sizeof(double) * 9 * (size_t)m->ngeom);
+    m->geom_lmat = (real *)malloc(sizeof(real) * 9 * (size_t)m->ngeom);
     for (int g = 0; g < m->ngeom; g++) quat2mat(m->geom_lmat + 9*g, m->geom_quat + 4*g);
     return m;
 }
-void ho_model_free(ho_model *m) { if (m) { free(m->geom_lmat); free(m->blob); free(m); } }
+void ho_model_free(ho_model *m) { if (m) { for (int i = 0; i < m->nconv; i++) free(m->conv[i]); free(m->geom_lmat); free(m->blob); free(m); } }
+int ho_real_bytes(void) { return (int)sizeof(real); }
 int ho_model_size(const ho_model *m, int which) { return m->sizes[which]; }
 
-#define ALLOC(field, n) d->field = (double *)calloc((size_t)(n) > 0 ? (size_t)(n) : 1, sizeof(double))
+#define ALLOC(field, n) d->field = (real *)calloc((size_t)(n) > 0 ? (size_t)(n) : 1, sizeof(real))
 ho_data *ho_data_new(const ho_model *m) {
     ho_data *d = (ho_data *)calloc(1, sizeof *d);
     int nv = m->nv, nl = m->nlink;
@@ -228,40 +256,40 @@ void ho_data_free(ho_data *d) {
 
 /* mj_resetData: qpos<-qpos0, qvel<-0, ctrl<-0, mocap_pos<-body pos (0 0 0), warmstart<-0, time<-0 */
 void ho_reset(const ho_model *m, ho_data *d) {
-    memcpy(d->qpos, m->qpos0, sizeof(double) * (size_t)m->nq);
-    memset(d->qvel, 0, sizeof(double) * (size_t)m->nv);
-    memset(d->ctrl, 0, sizeof(double) * (size_t)m->nu);
-    memset(d->qacc_warmstart, 0, sizeof(double) * (size_t)m->nv);
+    memcpy(d->qpos, m->qpos0, sizeof(real) * (size_t)m->nq);
+    memset(d->qvel, 0, sizeof(real) * (size_t)m->nv);
+    memset(d->ctrl, 0, sizeof(real) * (size_t)m->nu);
+    memset(d->qacc_warmstart, 0, sizeof(real) * (size_t)m->nv);
     d->mocap_pos[0] = d->mocap_pos[1] = d->mocap_pos[2] = 0;
     d->time = 0; d->bad = 0; d->ncon = 0; d->nefc = 0;
 }
 
 /* ------------------------------------------------------------------ a-2.1 kinematics */
 static void ho_kinematics(const ho_model *m, ho_data *d) {
-    double *xpos = d->xpos, *xquat = d->xquat, *xmat = d->xmat;
+    real *xpos = d->xpos, *xquat = d->xquat, *xmat = d->xmat;
     xpos[0]=xpos[1]=xpos[2]=0; xquat[0]=1; xquat[1]=xquat[2]=xquat[3]=0; quat2mat(xmat, xquat);
     for (int l = 1; l < m->nlink; l++) {
-        double *pos = xpos + 3*l, *quat = xquat + 4*l, *mat = xmat + 9*l;
+        real *pos = xpos + 3*l, *quat = xquat + 4*l, *mat = xmat + 9*l;
         if (m->link_free[l]) {
             int a = m->link_qposadr[l];
             quatnorm(d->qpos + a + 3);             /* mj_kinematics normalises free-joint quats in place */
             copy3(pos, d->qpos + a);
-            memcpy(quat, d->qpos + a + 3, 4 * sizeof(double));
+            memcpy(quat, d->qpos + a + 3, 4 * sizeof(real));
             quat2mat(mat, quat);
         } else {
             int p = m->link_parent[l];
-            double t[3];
+            real t[3];
             mulmv3(t, xmat + 9*p, m->link_pos + 3*l);
             add3(pos, xpos + 3*p, t);
             quatmul(quat, xquat + 4*p, m->link_quat + 4*l);
             quat2mat(mat, quat);
             for (int k = m->link_dofadr[l]; k < m->link_dofadr[l] + m->link_dofnum[l]; k++) {
-                double q = d->qpos[m->dof_qposadr[k]];
+                real q = d->qpos[m->dof_qposadr[k]];
                 if (m->dof_type[k] == DOF_SLIDE) {
                     mulmv3(t, mat, m->dof_axis + 3*k);
                     addscl3(pos, t, q);
                 } else {
-                    double anchor[3], qr[4], s = sin(0.5*q);
+                    real anchor[3], qr[4], s = sin(0.5*q);
                     mulmv3(t, mat, m->dof_pos + 3*k); add3(anchor, pos, t);
                     qr[0] = cos(0.5*q); qr[1] = m->dof_axis[3*k]*s; qr[2] = m->dof_axis[3*k+1]*s; qr[3] = m->dof_axis[3*k+2]*s;
                     quatmul(quat, quat, qr);
@@ -274,11 +302,11 @@ static void ho_kinematics(const ho_model *m, ho_data *d) {
     }
     /* world-frame motion axes per dof */
     for (int l = 1; l < m->nlink; l++) {
-        const double *mat = xmat + 9*l;
+        const real *mat = xmat + 9*l;
         int d0 = m->link_dofadr[l];
         if (m->link_free[l]) {
             for (int k = 0; k < 3; k++) {
-                double *lin = d->dof_lin + 3*(d0+k), *ang = d->dof_ang + 3*(d0+k);
+                real *lin = d->dof_lin + 3*(d0+k), *ang = d->dof_ang + 3*(d0+k);
                 lin[0]=lin[1]=lin[2]=0; lin[k]=1; ang[0]=ang[1]=ang[2]=0;
                 copy3(d->dof_anchor + 3*(d0+k), xpos + 3*l);
                 ang = d->dof_ang + 3*(d0+3+k); lin = d->dof_lin + 3*(d0+3+k);
@@ -287,7 +315,7 @@ static void ho_kinematics(const ho_model *m, ho_data *d) {
             }
         } else {
             for (int k = d0; k < d0 + m->link_dofnum[l]; k++) {
-                double ax[3], t[3];
+                real ax[3], t[3];
                 mulmv3(ax, mat, m->dof_axis + 3*k);
                 if (m->dof_type[k] == DOF_SLIDE) {
                     copy3(d->dof_lin + 3*k, ax); d->dof_ang[3*k]=d->dof_ang[3*k+1]=d->dof_ang[3*k+2]=0;
@@ -302,7 +330,7 @@ static void ho_kinematics(const ho_model *m, ho_data *d) {
     /* geom world frames */
     for (int g = 0; g < m->ngeom; g++) {
         int l = m->geom_link[g];
-        double t[3];
+        real t[3];
         mulmv3(t, xmat + 9*l, m->geom_pos + 3*g);
         add3(d->gpos + 3*g, xpos + 3*l, t);
         mulmm3(d->gmat + 9*g, xmat + 9*l, m->geom_lmat + 9*g);
@@ -310,37 +338,37 @@ static void ho_kinematics(const ho_model *m, ho_data *d) {
 }
 
 /* column k of the point Jacobian: velocity of world point p (attached below dof k) per unit qvel[k] */
-static inline void dof_point_vel(const ho_data *d, int k, const double *p, double *v) {
-    double r[3], c[3];
+static inline void dof_point_vel(const ho_data *d, int k, const real *p, real *v) {
+    real r[3], c[3];
     sub3(r, p, d->dof_anchor + 3*k);
     cross3(c, d->dof_ang + 3*k, r);
     add3(v, d->dof_lin + 3*k, c);
 }
 
 /* ------------------------------------------------------------------ a-2.2 inertia */
-static int cholesky(double *L, const double *A, int n) {
-    memcpy(L, A, sizeof(double) * (size_t)n * (size_t)n);
+static int cholesky(real *L, const real *A, int n) {
+    memcpy(L, A, sizeof(real) * (size_t)n * (size_t)n);
     for (int j = 0; j < n; j++) {
-        double s = L[j*n+j];
+        real s = L[j*n+j];
         for (int k = 0; k < j; k++) s -= L[j*n+k]*L[j*n+k];
         if (s < MINVAL) return -1;
         s = sqrt(s); L[j*n+j] = s;
         for (int i = j+1; i < n; i++) {
-            double t = L[i*n+j];
+            real t = L[i*n+j];
             for (int k = 0; k < j; k++) t -= L[i*n+k]*L[j*n+k];
             L[i*n+j] = t / s;
         }
     }
     return 0;
 }
-static void chol_solve(const double *L, int n, double *x) {
-    for (int i = 0; i < n; i++) { double s = x[i]; for (int k = 0; k < i; k++) s -= L[i*n+k]*x[k]; x[i] = s / L[i*n+i]; }
-    for (int i = n-1; i >= 0; i--) { double s = x[i]; for (int k = i+1; k < n; k++) s -= L[k*n+i]*x[k]; x[i] = s / L[i*n+i]; }
+static void chol_solve(const real *L, int n, real *x) {
+    for (int i = 0; i < n; i++) { real s = x[i]; for (int k = 0; k < i; k++) s -= L[i*n+k]*x[k]; x[i] = s / L[i*n+i]; }
+    for (int i = n-1; i >= 0; i--) { real s = x[i]; for (int k = i+1; k < n; k++) s -= L[k*n+i]*x[k]; x[i] = s / L[i*n+i]; }
 }
 
-static void link_world_inertia(const ho_model *m, const ho_data *d, int l, double *com, double *I) {
-    const double *mat = d->xmat + 9*l, *li = m->link_inertia + 6*l;
-    double t[3], Il[9] = { li[0], li[3], li[4], li[3], li[1], li[5], li[4], li[5], li[2] }, tmp[9], matT[9];
+static void link_world_inertia(const ho_model *m, const ho_data *d, int l, real *com, real *I) {
+    const real *mat = d->xmat + 9*l, *li = m->link_inertia + 6*l;
+    real t[3], Il[9] = { li[0], li[3], li[4], li[3], li[1], li[5], li[4], li[5], li[2] }, tmp[9], matT[9];
     mulmv3(t, mat, m->link_com + 3*l); add3(com, d->xpos + 3*l, t);
     for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) matT[3*i+j] = mat[3*j+i];
     mulmm3(tmp, mat, Il); mulmm3(I, tmp, matT);
@@ -348,9 +376,9 @@ static void link_world_inertia(const ho_model *m, const ho_data *d, int l, doubl
 
 static void ho_inertia(const ho_model *m, ho_data *d) {
     int nv = m->nv;
-    memset(d->M, 0, sizeof(double) * (size_t)nv * (size_t)nv);
+    memset(d->M, 0, sizeof(real) * (size_t)nv * (size_t)nv);
     for (int l = 1; l < m->nlink; l++) {
-        double com[3], I[9], jp[NV_MAX][3], jr[NV_MAX][3], Ijr[3];
+        real com[3], I[9], jp[NV_MAX][3], jr[NV_MAX][3], Ijr[3];
         int chain[NV_MAX], nc = 0;
         link_world_inertia(m, d, l, com, I);
         for (int k = m->link_dofadr[l] + m->link_dofnum[l] - 1; k >= 0; k = m->dof_parent[k]) chain[nc++] = k;
@@ -367,12 +395,12 @@ static void ho_inertia(const ho_model *m, ho_data *d) {
 /* ------------------------------------------------------------------ a-2.5 smooth dynamics */
 static void ho_smooth(const ho_model *m, ho_data *d) {
     int nv = m->nv;
-    const double grav[3] = { 0, 0, m->opt[OPT_GRAV_Z] };
+    const real grav[3] = { 0, 0, m->opt[OPT_GRAV_Z] };
     /* link velocities and bias accelerations (qacc = 0) */
-    memset(d->link_w, 0, sizeof(double)*3*(size_t)m->nlink); memset(d->link_vo, 0, sizeof(double)*3*(size_t)m->nlink);
-    memset(d->link_alpha, 0, sizeof(double)*3*(size_t)m->nlink); memset(d->link_ao, 0, sizeof(double)*3*(size_t)m->nlink);
+    memset(d->link_w, 0, sizeof(real)*3*(size_t)m->nlink); memset(d->link_vo, 0, sizeof(real)*3*(size_t)m->nlink);
+    memset(d->link_alpha, 0, sizeof(real)*3*(size_t)m->nlink); memset(d->link_ao, 0, sizeof(real)*3*(size_t)m->nlink);
     for (int l = 1; l < m->nlink; l++) {
-        double *w = d->link_w + 3*l, *vo = d->link_vo + 3*l, *al = d->link_alpha + 3*l, *ao = d->link_ao + 3*l;
+        real *w = d->link_w + 3*l, *vo = d->link_vo + 3*l, *al = d->link_alpha + 3*l, *ao = d->link_ao + 3*l;
         int d0 = m->link_dofadr[l];
         if (m->link_free[l]) {
             copy3(vo, d->qvel + d0);
@@ -380,8 +408,8 @@ static void ho_smooth(const ho_model *m, ho_data *d) {
             continue;                                        /* bias acceleration of the frame is zero */
         }
         int p = m->link_parent[l];
-        const double *wp = d->link_w + 3*p;
-        double r[3], t[3], t2[3];
+        const real *wp = d->link_w + 3*p;
+        real r[3], t[3], t2[3];
         /* the parent point that coincides with this link's origin *before* this link's joints act is
            not needed explicitly: use r = xpos_l - xpos_p (current), add joint-relative terms */
         sub3(r, d->xpos + 3*l, d->xpos + 3*p);
@@ -390,26 +418,26 @@ static void ho_smooth(const ho_model *m, ho_data *d) {
         cross3(t, d->link_alpha + 3*p, r); add3(ao, d->link_ao + 3*p, t);
         cross3(t, wp, r); cross3(t2, wp, t); add3(ao, ao, t2);
         for (int k = d0; k < d0 + m->link_dofnum[l]; k++) {
-            double qd = d->qvel[k];
+            real qd = d->qvel[k];
             if (m->dof_type[k] == DOF_SLIDE) {
-                const double *s = d->dof_lin + 3*k;
+                const real *s = d->dof_lin + 3*k;
                 addscl3(vo, s, qd);
                 cross3(t, wp, s); addscl3(ao, t, 2*qd);      /* Coriolis 2 w x (s qd) */
             } else {
-                const double *a = d->dof_ang + 3*k;
-                double rho[3];                               /* origin relative to anchor */
+                const real *a = d->dof_ang + 3*k;
+                real rho[3];                               /* origin relative to anchor */
                 sub3(rho, d->xpos + 3*l, d->dof_anchor + 3*k);
                 /* acceleration of origin: a_c + alpha x rho + w x (w x rho), with a_c the parent-point
                    acceleration at the anchor; rewrite relative to what is already in ao (computed at r) */
-                double wl[3], all[3], rc[3];
+                real wl[3], all[3], rc[3];
                 copy3(wl, w); addscl3(wl, a, qd);
                 cross3(t, w, a); copy3(all, al); addscl3(all, t, qd);   /* alpha += (w x a) qd */
                 /* parent-point acceleration at anchor c = origin - rho */
                 sub3(rc, r, rho);
-                double ac[3];
+                real ac[3];
                 cross3(t, d->link_alpha + 3*p, rc); add3(ac, d->link_ao + 3*p, t);
                 cross3(t, wp, rc); cross3(t2, wp, t); add3(ac, ac, t2);
-                double vc[3];
+                real vc[3];
                 cross3(t, wp, rc); add3(vc, d->link_vo + 3*p, t);
                 cross3(t, all, rho); add3(ao, ac, t);
                 cross3(t, wl, rho); cross3(t2, wl, t); add3(ao, ao, t2);
@@ -419,10 +447,10 @@ static void ho_smooth(const ho_model *m, ho_data *d) {
         }
     }
     /* bias = sum over links of J^T [m (a_com - g); I alpha + w x I w] */
-    memset(d->qfrc_bias, 0, sizeof(double) * (size_t)nv);
+    memset(d->qfrc_bias, 0, sizeof(real) * (size_t)nv);
     for (int l = 1; l < m->nlink; l++) {
-        double com[3], I[9], rc[3], t[3], t2[3], acom[3], F[3], N[3], Iw[3];
-        const double *w = d->link_w + 3*l, *al = d->link_alpha + 3*l;
+        real com[3], I[9], rc[3], t[3], t2[3], acom[3], F[3], N[3], Iw[3];
+        const real *w = d->link_w + 3*l, *al = d->link_alpha + 3*l;
         link_world_inertia(m, d, l, com, I);
         sub3(rc, com, d->xpos + 3*l);
         cross3(t, al, rc); add3(acom, d->link_ao + 3*l, t);
@@ -430,7 +458,7 @@ static void ho_smooth(const ho_model *m, ho_data *d) {
         sub3(t, acom, grav); scl3(F, t, m->link_mass[l]);
         mulmv3(N, I, al); mulmv3(Iw, I, w); cross3(t, w, Iw); add3(N, N, t);
         for (int k = m->link_dofadr[l] + m->link_dofnum[l] - 1; k >= 0; k = m->dof_parent[k]) {
-            double jp[3];
+            real jp[3];
             dof_point_vel(d, k, com, jp);
             d->qfrc_bias[k] += dot3(jp, F) + dot3(d->dof_ang + 3*k, N);
         }
@@ -439,9 +467,9 @@ static void ho_smooth(const ho_model *m, ho_data *d) {
     /* position actuators: force = kp*clamp(ctrl) - kp*gear*q, clamped to forcerange; qfrc = gear*force */
     for (int a = 0; a < m->nu; a++) {
         int k = m->act_dof[a];
-        double c = d->ctrl[a], lo = m->act_ctrlrange[2*a], hi = m->act_ctrlrange[2*a+1];
+        real c = d->ctrl[a], lo = m->act_ctrlrange[2*a], hi = m->act_ctrlrange[2*a+1];
         c = c < lo ? lo : (c > hi ? hi : c);
-        double f = m->act_kp[a] * c - m->act_kp[a] * m->act_gear[a] * d->qpos[m->dof_qposadr[k]];
+        real f = m->act_kp[a] * c - m->act_kp[a] * m->act_gear[a] * d->qpos[m->dof_qposadr[k]];
         lo = m->act_forcerange[2*a]; hi = m->act_forcerange[2*a+1];
         f = f < lo ? lo : (f > hi ? hi : f);
         d->qfrc_actuator[k] += m->act_gear[a] * f;
@@ -455,67 +483,67 @@ static void ho_smooth(const ho_model *m, ho_data *d) {
 
 /* ------------------------------------------------------------------ a-2.3 collision */
 /* mju_makeFrame: complete frame[0:3] (normal) with two tangents */
-static void make_frame(double *f) {
-    double *x = f, *y = f + 3, *z = f + 6;
+static void make_frame(real *f) {
+    real *x = f, *y = f + 3, *z = f + 6;
     if (x[1] > -0.5 && x[1] < 0.5) { y[0]=0; y[1]=1; y[2]=0; } else { y[0]=0; y[1]=0; y[2]=1; }
-    double dd = dot3(x, y);
+    real dd = dot3(x, y);
     addscl3(y, x, -dd); normalize3(y);
     cross3(z, x, y);
 }
 
-static int add_contact(const ho_model *m, ho_data *d, int pair, const double *pos, const double *n, double dist) {
+static int add_contact(const ho_model *m, ho_data *d, int pair, const real *pos, const real *n, real dist) {
     if (d->ncon >= m->nconmax) return 0;
     ho_contact *c = d->contact + d->ncon++;
     copy3(c->pos, pos); copy3(c->frame, n); make_frame(c->frame); c->dist = dist;
     c->pair = pair; c->geom1 = m->pair_geom1[pair]; c->geom2 = m->pair_geom2[pair];
     c->link1 = m->geom_link[c->geom1]; c->link2 = m->geom_link[c->geom2];
     c->dim = m->pair_condim[pair];
-    memcpy(c->friction, m->pair_friction + 5*pair, 5*sizeof(double));
-    memcpy(c->solref, m->pair_solref + 2*pair, 2*sizeof(double));
-    memcpy(c->solimp, m->pair_solimp + 5*pair, 5*sizeof(double));
+    memcpy(c->friction, m->pair_friction + 5*pair, 5*sizeof(real));
+    memcpy(c->solref, m->pair_solref + 2*pair, 2*sizeof(real));
+    memcpy(c->solimp, m->pair_solimp + 5*pair, 5*sizeof(real));
     return 1;
 }
 
 /* mjc_PlaneBox: corners below the plane, at most 4 */
 static void collide_plane_box(const ho_model *m, ho_data *d, int pair, int g1, int g2) {
-    const double *pp = d->gpos + 3*g1, *pm = d->gmat + 9*g1, *bp = d->gpos + 3*g2, *bm = d->gmat + 9*g2;
-    const double *s = m->geom_size + 3*g2;
-    double n[3] = { pm[2], pm[5], pm[8] };
+    const real *pp = d->gpos + 3*g1, *pm = d->gmat + 9*g1, *bp = d->gpos + 3*g2, *bm = d->gmat + 9*g2;
+    const real *s = m->geom_size + 3*g2;
+    real n[3] = { pm[2], pm[5], pm[8] };
     int cnt = 0;
     for (int i = 0; i < 8 && cnt < 4; i++) {
-        double loc[3] = { (i & 1 ? s[0] : -s[0]), (i & 2 ? s[1] : -s[1]), (i & 4 ? s[2] : -s[2]) }, c[3], r[3];
+        real loc[3] = { (i & 1 ? s[0] : -s[0]), (i & 2 ? s[1] : -s[1]), (i & 4 ? s[2] : -s[2]) }, c[3], r[3];
         mulmv3(c, bm, loc); add3(c, c, bp);
         sub3(r, c, pp);
-        double dist = dot3(r, n);
+        real dist = dot3(r, n);
         if (dist < 0) {
-            double pos[3]; copy3(pos, c); addscl3(pos, n, -0.5*dist);
+            real pos[3]; copy3(pos, c); addscl3(pos, n, -0.5*dist);
             cnt += add_contact(m, d, pair, pos, n, dist);
         }
     }
 }
 
 /* support point of a convex geom (box / cylinder / mesh hull) in world direction dir */
-static void support(const ho_model *m, const ho_data *d, int g, const double *dir, double *out) {
-    const double *mat = d->gmat + 9*g, *pos = d->gpos + 3*g, *s = m->geom_size + 3*g;
-    double dl[3], loc[3];
+static void support(const ho_model *m, const ho_data *d, int g, const real *dir, real *out) {
+    const real *mat = d->gmat + 9*g, *pos = d->gpos + 3*g, *s = m->geom_size + 3*g;
+    real dl[3], loc[3];
     mulmtv3(dl, mat, dir);
     switch (m->geom_type[g]) {
     case GEOM_BOX:
         loc[0] = dl[0] > 0 ? s[0] : -s[0]; loc[1] = dl[1] > 0 ? s[1] : -s[1]; loc[2] = dl[2] > 0 ? s[2] : -s[2];
         break;
     case GEOM_CYLINDER: {
-        double rr = sqrt(dl[0]*dl[0] + dl[1]*dl[1]);
+        real rr = sqrt(dl[0]*dl[0] + dl[1]*dl[1]);
         if (rr > MINVAL) { loc[0] = dl[0]/rr*s[0]; loc[1] = dl[1]/rr*s[0]; } else { loc[0] = loc[1] = 0; }
         loc[2] = dl[2] > 0 ? s[1] : -s[1];
         break; }
     case GEOM_SPHERE:
-        { double t[3]; copy3(t, dl); normalize3(t); scl3(loc, t, s[0]); }
+        { real t[3]; copy3(t, dl); normalize3(t); scl3(loc, t, s[0]); }
         break;
     default: { /* mesh: exhaustive search over hull vertices, first maximum wins */
-        const double *v = m->mesh_vert + 3*m->geom_meshadr[g];
-        int best = 0; double bd = -1e300;
+        const real *v = m->mesh_vert + 3*m->geom_meshadr[g];
+        int best = 0; real bd = -1e300;
         for (int i = 0; i < m->geom_meshnum[g]; i++) {
-            double t = dot3(v + 3*i, dl);
+            real t = dot3(v + 3*i, dl);
             if (t > bd) { bd = t; best = i; }
         }
         copy3(loc, v + 3*best);
@@ -533,46 +561,46 @@ static void support(const ho_model *m, const ho_data *d, int g, const double *di
 #define PLANE_CONVEX_TILT 0.1
 #define PLANE_CONVEX_DUP 1e-5
 static void collide_plane_convex(const ho_model *m, ho_data *d, int pair, int g1, int g2) {
-    const double *pp = d->gpos + 3*g1, *pm = d->gmat + 9*g1;
-    double n[3] = { pm[2], pm[5], pm[8] }, nn[3] = { -pm[2], -pm[5], -pm[8] }, p[3], r[3];
+    const real *pp = d->gpos + 3*g1, *pm = d->gmat + 9*g1;
+    real n[3] = { pm[2], pm[5], pm[8] }, nn[3] = { -pm[2], -pm[5], -pm[8] }, p[3], r[3];
     support(m, d, g2, nn, p);
     sub3(r, p, pp);
-    double dist = dot3(r, n);
+    real dist = dot3(r, n);
     if (!(dist < 0)) return;
-    { double pos[3]; copy3(pos, p); addscl3(pos, n, -0.5*dist); add_contact(m, d, pair, pos, n, dist); }
+    { real pos[3]; copy3(pos, p); addscl3(pos, n, -0.5*dist); add_contact(m, d, pair, pos, n, dist); }
     const int maxcnt = m->pair_slot[pair+1] - m->pair_slot[pair];
     if (maxcnt <= 1) return;
-    double fr[9], kept[4][3]; int nk = 1;
+    real fr[9], kept[4][3]; int nk = 1;
     copy3(fr, n); make_frame(fr);
     copy3(kept[0], p);
-    static const double cs[3][2] = { {1.0, 0.0}, {-0.5, 0.8660254037844386}, {-0.5, -0.8660254037844386} };
+    static const real cs[3][2] = { {1.0, 0.0}, {-0.5, 0.8660254037844386}, {-0.5, -0.8660254037844386} };
     for (int i = 0; i < 3 && nk < maxcnt; i++) {
-        double dir[3], q[3];
+        real dir[3], q[3];
         for (int k = 0; k < 3; k++) dir[k] = nn[k] + PLANE_CONVEX_TILT * (cs[i][0]*fr[3+k] + cs[i][1]*fr[6+k]);
         support(m, d, g2, dir, q);
         sub3(r, q, pp);
-        const double dq = dot3(r, n);
+        const real dq = dot3(r, n);
         if (!(dq < 0)) continue;
         int dup = 0;
-        for (int j = 0; j < nk; j++) { double e[3]; sub3(e, q, kept[j]); if (dot3(e, e) < PLANE_CONVEX_DUP*PLANE_CONVEX_DUP) dup = 1; }
+        for (int j = 0; j < nk; j++) { real e[3]; sub3(e, q, kept[j]); if (dot3(e, e) < PLANE_CONVEX_DUP*PLANE_CONVEX_DUP) dup = 1; }
         if (dup) continue;
-        double pos[3]; copy3(pos, q); addscl3(pos, n, -0.5*dq);
+        real pos[3]; copy3(pos, q); addscl3(pos, n, -0.5*dq);
         add_contact(m, d, pair, pos, n, dq);
         copy3(kept[nk++], q);
     }
 }
 
 /* --- box-box: separating-axis test + reference-face clipping (up to 8 points) */
-static int clip_poly(double (*poly)[3], int n, const double *axis, double lim, const double *origin) {
+static int clip_poly(real (*poly)[3], int n, const real *axis, real lim, const real *origin) {
     /* keep the part with (p-origin).axis <= lim ; Sutherland-Hodgman */
-    double out[16][3]; int no = 0;
+    real out[16][3]; int no = 0;
     for (int i = 0; i < n; i++) {
-        const double *a = poly[i], *b = poly[(i+1) % n];
-        double ra[3], rb[3]; sub3(ra, a, origin); sub3(rb, b, origin);
-        double da = dot3(ra, axis) - lim, db = dot3(rb, axis) - lim;
+        const real *a = poly[i], *b = poly[(i+1) % n];
+        real ra[3], rb[3]; sub3(ra, a, origin); sub3(rb, b, origin);
+        real da = dot3(ra, axis) - lim, db = dot3(rb, axis) - lim;
         if (da <= 0) { copy3(out[no++], a); }
         if ((da < 0 && db > 0) || (da > 0 && db < 0)) {
-            double t = da / (da - db);
+            real t = da / (da - db);
             out[no][0] = a[0] + t*(b[0]-a[0]); out[no][1] = a[1] + t*(b[1]-a[1]); out[no][2] = a[2] + t*(b[2]-a[2]); no++;
         }
     }
@@ -581,82 +609,82 @@ static int clip_poly(double (*poly)[3], int n, const double *axis, double lim, c
 }
 
 static void collide_box_box(const ho_model *m, ho_data *d, int pair, int g1, int g2) {
-    const double *p1 = d->gpos + 3*g1, *R1 = d->gmat + 9*g1, *s1 = m->geom_size + 3*g1;
-    const double *p2 = d->gpos + 3*g2, *R2 = d->gmat + 9*g2, *s2 = m->geom_size + 3*g2;
-    double A[3][3], B[3][3], C[3][3], aC[3][3], dv[3];
+    const real *p1 = d->gpos + 3*g1, *R1 = d->gmat + 9*g1, *s1 = m->geom_size + 3*g1;
+    const real *p2 = d->gpos + 3*g2, *R2 = d->gmat + 9*g2, *s2 = m->geom_size + 3*g2;
+    real A[3][3], B[3][3], C[3][3], aC[3][3], dv[3];
     for (int i = 0; i < 3; i++) for (int k = 0; k < 3; k++) { A[i][k] = R1[3*k+i]; B[i][k] = R2[3*k+i]; }
     sub3(dv, p2, p1);
     for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { C[i][j] = dot3(A[i], B[j]); aC[i][j] = fabs(C[i][j]); }
-    double best = -1e300; int code = -1; double bestn[3] = {0,0,0};
+    real best = -1e300; int code = -1; real bestn[3] = {0,0,0};
     /* face axes of box 1, then box 2: first strictly-better axis wins (box 1 preferred on ties) */
     for (int i = 0; i < 3; i++) {
-        double t = dot3(dv, A[i]);
-        double sep = fabs(t) - (s1[i] + s2[0]*aC[i][0] + s2[1]*aC[i][1] + s2[2]*aC[i][2]);
+        real t = dot3(dv, A[i]);
+        real sep = fabs(t) - (s1[i] + s2[0]*aC[i][0] + s2[1]*aC[i][1] + s2[2]*aC[i][2]);
         if (sep > 0) return;
         if (sep > best) { best = sep; code = i; scl3(bestn, A[i], t < 0 ? -1.0 : 1.0); }
     }
     for (int j = 0; j < 3; j++) {
-        double t = dot3(dv, B[j]);
-        double sep = fabs(t) - (s2[j] + s1[0]*aC[0][j] + s1[1]*aC[1][j] + s1[2]*aC[2][j]);
+        real t = dot3(dv, B[j]);
+        real sep = fabs(t) - (s2[j] + s1[0]*aC[0][j] + s1[1]*aC[1][j] + s1[2]*aC[2][j]);
         if (sep > 0) return;
         if (sep > best) { best = sep; code = 3 + j; scl3(bestn, B[j], t < 0 ? -1.0 : 1.0); }
     }
     /* edge x edge axes; must beat the best face axis by 5 % + 1e-9 to be chosen */
     for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
-        double L[3]; cross3(L, A[i], B[j]);
-        double ln = norm3(L);
+        real L[3]; cross3(L, A[i], B[j]);
+        real ln = norm3(L);
         if (ln < 1e-6) continue;
         scl3(L, L, 1.0/ln);
-        double t = dot3(dv, L), ra = 0, rb = 0;
+        real t = dot3(dv, L), ra = 0, rb = 0;
         for (int k = 0; k < 3; k++) { ra += s1[k]*fabs(dot3(A[k], L)); rb += s2[k]*fabs(dot3(B[k], L)); }
-        double sep = fabs(t) - (ra + rb);
+        real sep = fabs(t) - (ra + rb);
         if (sep > 0) return;
         if (sep * 1.05 > best + 1e-9) { best = sep / 1.0; code = 6 + 3*i + j; scl3(bestn, L, t < 0 ? -1.0 : 1.0); }
     }
     if (code < 6) {
         /* reference face on box `ref`, incident face on the other */
         int ref1 = code < 3;
-        const double *pr = ref1 ? p1 : p2, *pi = ref1 ? p2 : p1, *sr = ref1 ? s1 : s2, *si = ref1 ? s2 : s1;
-        double (*Ar)[3] = ref1 ? A : B, (*Ai)[3] = ref1 ? B : A;
+        const real *pr = ref1 ? p1 : p2, *pi = ref1 ? p2 : p1, *sr = ref1 ? s1 : s2, *si = ref1 ? s2 : s1;
+        real (*Ar)[3] = ref1 ? A : B, (*Ai)[3] = ref1 ? B : A;
         int ax = ref1 ? code : code - 3;
-        double nref[3]; scl3(nref, bestn, ref1 ? 1.0 : -1.0);   /* outward normal of the reference face */
+        real nref[3]; scl3(nref, bestn, ref1 ? 1.0 : -1.0);   /* outward normal of the reference face */
         /* incident face: most anti-parallel to nref */
-        int jx = 0; double bd = -1;
-        for (int j = 0; j < 3; j++) { double t = fabs(dot3(nref, Ai[j])); if (t > bd) { bd = t; jx = j; } }
-        double sgn = dot3(nref, Ai[jx]) > 0 ? -1.0 : 1.0;
+        int jx = 0; real bd = -1;
+        for (int j = 0; j < 3; j++) { real t = fabs(dot3(nref, Ai[j])); if (t > bd) { bd = t; jx = j; } }
+        real sgn = dot3(nref, Ai[jx]) > 0 ? -1.0 : 1.0;
         int j1 = (jx + 1) % 3, j2 = (jx + 2) % 3;
-        double fc[3]; copy3(fc, pi); addscl3(fc, Ai[jx], sgn * si[jx]);
-        double poly[16][3];
-        const double sg[4][2] = { {1,1}, {-1,1}, {-1,-1}, {1,-1} };
+        real fc[3]; copy3(fc, pi); addscl3(fc, Ai[jx], sgn * si[jx]);
+        real poly[16][3];
+        const real sg[4][2] = { {1,1}, {-1,1}, {-1,-1}, {1,-1} };
         for (int k = 0; k < 4; k++) { copy3(poly[k], fc); addscl3(poly[k], Ai[j1], sg[k][0]*si[j1]); addscl3(poly[k], Ai[j2], sg[k][1]*si[j2]); }
         int np = 4, u = (ax + 1) % 3, v = (ax + 2) % 3;
-        double neg[3];
+        real neg[3];
         np = clip_poly(poly, np, Ar[u], sr[u], pr); if (np) { scl3(neg, Ar[u], -1); np = clip_poly(poly, np, neg, sr[u], pr); }
         if (np) np = clip_poly(poly, np, Ar[v], sr[v], pr);
         if (np) { scl3(neg, Ar[v], -1); np = clip_poly(poly, np, neg, sr[v], pr); }
-        double n12[3]; copy3(n12, bestn);                      /* from geom1 to geom2 */
+        real n12[3]; copy3(n12, bestn);                      /* from geom1 to geom2 */
         int cnt = 0;
         for (int k = 0; k < np && cnt < 8; k++) {
-            double r[3]; sub3(r, poly[k], pr);
-            double dist = dot3(r, nref) - sr[ax];               /* signed distance to the reference face */
+            real r[3]; sub3(r, poly[k], pr);
+            real dist = dot3(r, nref) - sr[ax];               /* signed distance to the reference face */
             if (dist < 0) {
-                double pos[3]; copy3(pos, poly[k]); addscl3(pos, nref, -0.5*dist);
+                real pos[3]; copy3(pos, poly[k]); addscl3(pos, nref, -0.5*dist);
                 cnt += add_contact(m, d, pair, pos, n12, dist);
             }
         }
     } else {
         int i = (code - 6) / 3, j = (code - 6) % 3;
-        double pa[3], pb[3];
+        real pa[3], pb[3];
         copy3(pa, p1); copy3(pb, p2);
         for (int k = 0; k < 3; k++) {
             if (k != i) addscl3(pa, A[k], (dot3(bestn, A[k]) > 0 ? 1.0 : -1.0) * s1[k]);
             if (k != j) addscl3(pb, B[k], (dot3(bestn, B[k]) > 0 ? -1.0 : 1.0) * s2[k]);
         }
         /* closest points of lines pa + t A_i and pb + u B_j */
-        double w[3]; sub3(w, pa, pb);
-        double b = C[i][j], dd = dot3(A[i], w), e = dot3(B[j], w), den = 1 - b*b;
-        double t = den > 1e-12 ? (b*e - dd) / den : 0, uu = den > 1e-12 ? (e - b*dd) / den : 0;
-        double qa[3], qb[3], pos[3];
+        real w[3]; sub3(w, pa, pb);
+        real b = C[i][j], dd = dot3(A[i], w), e = dot3(B[j], w), den = 1 - b*b;
+        real t = den > 1e-12 ? (b*e - dd) / den : 0, uu = den > 1e-12 ? (e - b*dd) / den : 0;
+        real qa[3], qb[3], pos[3];
         copy3(qa, pa); addscl3(qa, A[i], t); copy3(qb, pb); addscl3(qb, B[j], uu);
         add3(pos, qa, qb); scl3(pos, pos, 0.5);
         add_contact(m, d, pair, pos, bestn, best);
@@ -665,57 +693,57 @@ static void collide_box_box(const ho_model *m, ho_data *d, int pair, int g1, int
 
 /* --- convex-convex: Minkowski Portal Refinement (restates libccd's ccdMPRPenetration, used by
  *     MuJoCo's mjc_Convex); one contact per pair */
-typedef struct { double v[3], v1[3], v2[3]; } mpr_sup;
+typedef struct { real v[3], v1[3], v2[3]; } mpr_sup;
 /* diagnostics: support-pair evaluations of the last / all MPR calls (not thread safe; tests only) */
 static long ho_dbg_mpr_supports_ = 0, ho_dbg_mpr_calls_ = 0, ho_dbg_mpr_max_ = 0, ho_dbg_mpr_cur_ = 0;
 long ho_dbg_mpr_supports(void) { return ho_dbg_mpr_supports_; }
 long ho_dbg_mpr_calls(void) { return ho_dbg_mpr_calls_; }
 long ho_dbg_mpr_max(void) { return ho_dbg_mpr_max_; }
-static void mpr_support(const ho_model *m, const ho_data *d, int g1, int g2, const double *dir, mpr_sup *s) {
+static void mpr_support(const ho_model *m, const ho_data *d, int g1, int g2, const real *dir, mpr_sup *s) {
     ho_dbg_mpr_supports_++; ho_dbg_mpr_cur_++;
-    double nd[3] = { -dir[0], -dir[1], -dir[2] };
+    real nd[3] = { -dir[0], -dir[1], -dir[2] };
     support(m, d, g1, dir, s->v1); support(m, d, g2, nd, s->v2); sub3(s->v, s->v1, s->v2);
 }
-static double point_seg_dist2(const double *P, const double *x0, const double *b, double *wit) {
-    double dd[3], a[3]; sub3(dd, b, x0); sub3(a, x0, P);
-    double t = -dot3(a, dd) / dot3(dd, dd), w[3];
+static real point_seg_dist2(const real *P, const real *x0, const real *b, real *wit) {
+    real dd[3], a[3]; sub3(dd, b, x0); sub3(a, x0, P);
+    real t = -dot3(a, dd) / dot3(dd, dd), w[3];
     if (t < 0 || fabs(t) < 1e-300) { copy3(w, x0); }
     else if (t > 1 || t == 1) { copy3(w, b); }
     else { copy3(w, x0); addscl3(w, dd, t); }
     if (wit) copy3(wit, w);
-    double r[3]; sub3(r, w, P); return dot3(r, r);
+    real r[3]; sub3(r, w, P); return dot3(r, r);
 }
-static double point_tri_dist2(const double *P, const double *x0, const double *B, const double *Cc, double *wit) {
-    double d1[3], d2[3], a[3];
+static real point_tri_dist2(const real *P, const real *x0, const real *B, const real *Cc, real *wit) {
+    real d1[3], d2[3], a[3];
     sub3(d1, B, x0); sub3(d2, Cc, x0); sub3(a, x0, P);
-    double u = dot3(a, a), v = dot3(d1, d1), w = dot3(d2, d2), p = dot3(a, d1), q = dot3(a, d2), r = dot3(d1, d2);
-    double den = w*v - r*r, s = -1, t = -1;
+    real u = dot3(a, a), v = dot3(d1, d1), w = dot3(d2, d2), p = dot3(a, d1), q = dot3(a, d2), r = dot3(d1, d2);
+    real den = w*v - r*r, s = -1, t = -1;
     if (fabs(den) > 0) { s = (q*r - w*p) / den; t = (-s*r - q) / w; }
     if (s >= 0 && s <= 1 && t >= 0 && t <= 1 && t + s <= 1) {
         if (wit) { copy3(wit, x0); addscl3(wit, d1, s); addscl3(wit, d2, t); }
-        double dist = s*s*v + t*t*w + 2*s*t*r + 2*s*p + 2*t*q + u;
+        real dist = s*s*v + t*t*w + 2*s*t*r + 2*s*p + 2*t*q + u;
         return dist < 0 ? 0 : dist;
     }
-    double w2[3], best = point_seg_dist2(P, x0, B, wit), dist;
+    real w2[3], best = point_seg_dist2(P, x0, B, wit), dist;
     dist = point_seg_dist2(P, x0, Cc, w2); if (dist < best) { best = dist; if (wit) copy3(wit, w2); }
     dist = point_seg_dist2(P, B, Cc, w2); if (dist < best) { best = dist; if (wit) copy3(wit, w2); }
     return best;
 }
-static void portal_dir(const mpr_sup *p, double *dir) {
-    double a[3], b[3]; sub3(a, p[2].v, p[1].v); sub3(b, p[3].v, p[1].v); cross3(dir, a, b); normalize3(dir);
+static void portal_dir(const mpr_sup *p, real *dir) {
+    real a[3], b[3]; sub3(a, p[2].v, p[1].v); sub3(b, p[3].v, p[1].v); cross3(dir, a, b); normalize3(dir);
 }
 static void expand_portal(mpr_sup *p, const mpr_sup *v4) {
-    double v4v0[3]; cross3(v4v0, v4->v, p[0].v);
+    real v4v0[3]; cross3(v4v0, v4->v, p[0].v);
     if (dot3(p[1].v, v4v0) > 0) { if (dot3(p[2].v, v4v0) > 0) p[1] = *v4; else p[3] = *v4; }
     else { if (dot3(p[3].v, v4v0) > 0) p[2] = *v4; else p[1] = *v4; }
 }
-static int portal_reach_tol(const mpr_sup *p, const mpr_sup *v4, const double *dir, double tol) {
-    double dv4 = dot3(v4->v, dir), d1 = dv4 - dot3(p[1].v, dir), d2 = dv4 - dot3(p[2].v, dir), d3 = dv4 - dot3(p[3].v, dir);
-    double mn = d1 < d2 ? d1 : d2; mn = mn < d3 ? mn : d3;
+static int portal_reach_tol(const mpr_sup *p, const mpr_sup *v4, const real *dir, real tol) {
+    real dv4 = dot3(v4->v, dir), d1 = dv4 - dot3(p[1].v, dir), d2 = dv4 - dot3(p[2].v, dir), d3 = dv4 - dot3(p[3].v, dir);
+    real mn = d1 < d2 ? d1 : d2; mn = mn < d3 ? mn : d3;
     return mn < tol;
 }
-static void mpr_find_pos(const mpr_sup *p, double *pos) {
-    double dir[3], b[4], t[3], sum;
+static void mpr_find_pos(const mpr_sup *p, real *pos) {
+    real dir[3], b[4], t[3], sum;
     portal_dir(p, dir);
     cross3(t, p[1].v, p[2].v); b[0] = dot3(t, p[3].v);
     cross3(t, p[3].v, p[2].v); b[1] = dot3(t, p[0].v);
@@ -729,16 +757,16 @@ static void mpr_find_pos(const mpr_sup *p, double *pos) {
         cross3(t, p[1].v, p[2].v); b[3] = dot3(t, dir);
         sum = b[1] + b[2] + b[3];
     }
-    double inv = 1.0 / sum, p1[3] = {0,0,0}, p2[3] = {0,0,0};
+    real inv = 1.0 / sum, p1[3] = {0,0,0}, p2[3] = {0,0,0};
     for (int i = 0; i < 4; i++) { addscl3(p1, p[i].v1, b[i]); addscl3(p2, p[i].v2, b[i]); }
     for (int k = 0; k < 3; k++) pos[k] = 0.5 * inv * (p1[k] + p2[k]);
 }
 /* returns 1 and fills depth/dir/pos when the geoms penetrate */
-static int mpr_penetration(const ho_model *m, const ho_data *d, int g1, int g2, double *depth, double *dirout, double *pos) {
-    const double eps = 2.220446049250313e-16, tol = m->opt[OPT_MPR_TOLERANCE];
+static int mpr_penetration(const ho_model *m, const ho_data *d, int g1, int g2, real *depth, real *dirout, real *pos) {
+    const real eps = 2.220446049250313e-16, tol = m->opt[OPT_MPR_TOLERANCE];
     const int maxit = (int)m->opt[OPT_MPR_ITERATIONS];
     mpr_sup p[4], v4;
-    double dir[3], va[3], vb[3], dt;
+    real dir[3], va[3], vb[3], dt;
     /* discover portal */
     copy3(p[0].v1, d->gpos + 3*g1); copy3(p[0].v2, d->gpos + 3*g2); sub3(p[0].v, p[0].v1, p[0].v2);
     if (fabs(p[0].v[0]) < eps && fabs(p[0].v[1]) < eps && fabs(p[0].v[2]) < eps) p[0].v[0] += 1e-5;
@@ -749,7 +777,7 @@ static int mpr_penetration(const ho_model *m, const ho_data *d, int g1, int g2, 
     cross3(dir, p[0].v, p[1].v);
     if (dot3(dir, dir) < eps*eps) {
         /* origin on the v0-v1 segment: touching (depth 0) or segment penetration */
-        double l1 = norm3(p[1].v);
+        real l1 = norm3(p[1].v);
         if (l1 < eps) return 0;
         *depth = l1; copy3(dirout, p[1].v); normalize3(dirout);
         for (int k = 0; k < 3; k++) pos[k] = 0.5 * (p[1].v1[k] + p[1].v2[k]);
@@ -789,7 +817,7 @@ static int mpr_penetration(const ho_model *m, const ho_data *d, int g1, int g2, 
         portal_dir(p, dir);
         mpr_support(m, d, g1, g2, dir, &v4);
         if (portal_reach_tol(p, &v4, dir, tol) || it > maxit) {
-            double org[3] = {0,0,0}, pdir[3];
+            real org[3] = {0,0,0}, pdir[3];
             *depth = sqrt(point_tri_dist2(org, p[1].v, p[2].v, p[3].v, pdir));
             if (fabs(pdir[0]) < eps && fabs(pdir[1]) < eps && fabs(pdir[2]) < eps) copy3(pdir, dir);
             normalize3(pdir); copy3(dirout, pdir);
@@ -800,7 +828,7 @@ static int mpr_penetration(const ho_model *m, const ho_data *d, int g1, int g2, 
     }
 }
 static void collide_convex(const ho_model *m, ho_data *d, int pair, int g1, int g2) {
-    double depth, dir[3], pos[3];
+    real depth, dir[3], pos[3];
     ho_dbg_mpr_calls_++; ho_dbg_mpr_cur_ = 0;
     if (mpr_penetration(m, d, g1, g2, &depth, dir, pos)) add_contact(m, d, pair, pos, dir, -depth);
     if (ho_dbg_mpr_cur_ > ho_dbg_mpr_max_) ho_dbg_mpr_max_ = ho_dbg_mpr_cur_;
@@ -812,12 +840,12 @@ static void ho_collision(const ho_model *m, ho_data *d) {
         int g1 = m->pair_geom1[p], g2 = m->pair_geom2[p];
         /* mj_collideGeoms bounding test (margin 0) */
         if (m->geom_type[g1] == GEOM_PLANE) {
-            const double *pm = d->gmat + 9*g1; double n[3] = { pm[2], pm[5], pm[8] }, r[3];
+            const real *pm = d->gmat + 9*g1; real n[3] = { pm[2], pm[5], pm[8] }, r[3];
             sub3(r, d->gpos + 3*g2, d->gpos + 3*g1);
             if (dot3(r, n) > m->geom_rbound[g2]) continue;
         } else {
-            double r[3]; sub3(r, d->gpos + 3*g2, d->gpos + 3*g1);
-            double bound = m->geom_rbound[g1] + m->geom_rbound[g2];
+            real r[3]; sub3(r, d->gpos + 3*g2, d->gpos + 3*g1);
+            real bound = m->geom_rbound[g1] + m->geom_rbound[g2];
             if (dot3(r, r) > bound*bound) continue;
         }
         switch (m->pair_fn[p]) {
@@ -830,15 +858,15 @@ static void ho_collision(const ho_model *m, ho_data *d) {
 }
 
 /* ------------------------------------------------------------------ a-2.4 constraints */
-static double impedance(const double *solimp, double pos) {
-    double dmin = solimp[0], dmax = solimp[1], width = solimp[2], mid = solimp[3], power = solimp[4];
+static real impedance(const real *solimp, real pos) {
+    real dmin = solimp[0], dmax = solimp[1], width = solimp[2], mid = solimp[3], power = solimp[4];
     dmin = dmin < MINIMP ? MINIMP : (dmin > MAXIMP ? MAXIMP : dmin);
     dmax = dmax < MINIMP ? MINIMP : (dmax > MAXIMP ? MAXIMP : dmax);
     width = width < MINVAL ? MINVAL : width;
     mid = mid < MINIMP ? MINIMP : (mid > MAXIMP ? MAXIMP : mid);
     power = power < 1 ? 1 : power;
     if (dmin == dmax || width <= MINVAL) return 0.5*(dmin + dmax);
-    double x = fabs(pos) / width, y;
+    real x = fabs(pos) / width, y;
     if (x >= 1) return dmax;
     if (x <= 0) return dmin;
     if (power == 1) y = x;
@@ -847,12 +875,12 @@ static double impedance(const double *solimp, double pos) {
     return dmin + y*(dmax - dmin);
 }
 
-static void point_jac_row(const ho_model *m, const ho_data *d, int link, const double *pt,
-                          const double *dirp, const double *dirr, double sign, double *row) {
+static void point_jac_row(const ho_model *m, const ho_data *d, int link, const real *pt,
+                          const real *dirp, const real *dirr, real sign, real *row) {
     /* row += sign * (dirp . jacp + dirr . jacr) for a point on `link` */
     if (link == 0) return;
     for (int k = m->link_dofadr[link] + m->link_dofnum[link] - 1; k >= 0; k = m->dof_parent[k]) {
-        double v[3], acc = 0;
+        real v[3], acc = 0;
         if (dirp) { dof_point_vel(d, k, pt, v); acc += dot3(v, dirp); }
         if (dirr) acc += dot3(d->dof_ang + 3*k, dirr);
         row[k] += sign * acc;
@@ -861,24 +889,24 @@ static void point_jac_row(const ho_model *m, const ho_data *d, int link, const d
 
 static void ho_make_constraint(const ho_model *m, ho_data *d) {
     int nv = m->nv, ne = 0;
-    double impratio = m->opt[OPT_IMPRATIO];
+    real impratio = m->opt[OPT_IMPRATIO];
     /* joint limits (mj_instantiateLimit): lower side then upper side */
     for (int k = 0; k < nv && ne < m->njmax; k++) {
         if (!m->dof_limited[k]) continue;
-        double q = d->qpos[m->dof_qposadr[k]];
+        real q = d->qpos[m->dof_qposadr[k]];
         for (int side = 0; side < 2; side++) {
-            double dist = side == 0 ? q - m->dof_range[2*k] : m->dof_range[2*k+1] - q;
+            real dist = side == 0 ? q - m->dof_range[2*k] : m->dof_range[2*k+1] - q;
             if (dist < 0 && ne < m->njmax) {
-                double *row = d->efc_J + (size_t)ne*nv;
-                memset(row, 0, sizeof(double)*(size_t)nv);
+                real *row = d->efc_J + (size_t)ne*nv;
+                memset(row, 0, sizeof(real)*(size_t)nv);
                 row[k] = side == 0 ? 1.0 : -1.0;
-                double imp = impedance(m->dof_solimp + 5*k, dist), dmax = m->dof_solimp[5*k+1];
-                double tc = m->dof_solref[2*k], dr = m->dof_solref[2*k+1];
+                real imp = impedance(m->dof_solimp + 5*k, dist), dmax = m->dof_solimp[5*k+1];
+                real tc = m->dof_solref[2*k], dr = m->dof_solref[2*k+1];
                 dmax = dmax < MINIMP ? MINIMP : (dmax > MAXIMP ? MAXIMP : dmax);
                 d->efc_pos[ne] = dist; d->efc_type[ne] = 0;
                 d->efc_K[ne] = imp / (dmax*dmax*tc*tc*dr*dr);  /* K * imp folded together */
                 d->efc_B[ne] = 2.0 / (dmax*tc);
-                double R = (1 - imp)/imp * m->dof_invweight0[k];
+                real R = (1 - imp)/imp * m->dof_invweight0[k];
                 d->efc_R[ne] = R < MINVAL ? MINVAL : R;
                 ne++;
             }
@@ -891,22 +919,22 @@ static void ho_make_constraint(const ho_model *m, ho_data *d) {
         int dim = con->dim;
         if (ne + dim > m->njmax) { d->ncon = c; break; }
         con->efc_address = ne;
-        double imp = impedance(con->solimp, con->dist), dmax = con->solimp[1];
+        real imp = impedance(con->solimp, con->dist), dmax = con->solimp[1];
         dmax = dmax < MINIMP ? MINIMP : (dmax > MAXIMP ? MAXIMP : dmax);
-        double tc = con->solref[0], dr = con->solref[1];
-        double tran = m->geom_invweight[2*con->geom1] + m->geom_invweight[2*con->geom2];
-        double rot = m->geom_invweight[2*con->geom1+1] + m->geom_invweight[2*con->geom2+1];
+        real tc = con->solref[0], dr = con->solref[1];
+        real tran = m->geom_invweight[2*con->geom1] + m->geom_invweight[2*con->geom2];
+        real rot = m->geom_invweight[2*con->geom1+1] + m->geom_invweight[2*con->geom2+1];
         for (int j = 0; j < dim; j++) {
-            double *row = d->efc_J + (size_t)(ne+j)*nv;
-            memset(row, 0, sizeof(double)*(size_t)nv);
-            const double *ax = con->frame + 3*(j % 3);
+            real *row = d->efc_J + (size_t)(ne+j)*nv;
+            memset(row, 0, sizeof(real)*(size_t)nv);
+            const real *ax = con->frame + 3*(j % 3);
             if (j < 3) { point_jac_row(m, d, con->link2, con->pos, ax, NULL, 1.0, row); point_jac_row(m, d, con->link1, con->pos, ax, NULL, -1.0, row); }
             else { point_jac_row(m, d, con->link2, con->pos, NULL, ax, 1.0, row); point_jac_row(m, d, con->link1, con->pos, NULL, ax, -1.0, row); }
             d->efc_pos[ne+j] = j == 0 ? con->dist : 0.0;
             d->efc_type[ne+j] = j == 0 ? 1 : 2;
             d->efc_K[ne+j] = j == 0 ? imp / (dmax*dmax*tc*tc*dr*dr) : 0.0;   /* friction rows: K = 0 */
             d->efc_B[ne+j] = 2.0 / (dmax*tc);
-            double R = (1 - imp)/imp * (j < 3 ? tran : rot);
+            real R = (1 - imp)/imp * (j < 3 ? tran : rot);
             d->efc_R[ne+j] = R < MINVAL ? MINVAL : R;
         }
         /* elliptic-cone regulariser adjustment */
@@ -921,7 +949,7 @@ static void ho_make_constraint(const ho_model *m, ho_data *d) {
     d->nefc = ne;
     /* mj_referenceConstraint: aref = -B*(J qvel) - K*imp*(pos - margin) */
     for (int i = 0; i < ne; i++) {
-        double v = 0; const double *row = d->efc_J + (size_t)i*nv;
+        real v = 0; const real *row = d->efc_J + (size_t)i*nv;
         for (int k = 0; k < nv; k++) v += row[k]*d->qvel[k];
         d->efc_vel[i] = v;
         d->efc_aref[i] = -d->efc_B[i]*v - d->efc_K[i]*d->efc_pos[i];
@@ -931,28 +959,28 @@ static void ho_make_constraint(const ho_model *m, ho_data *d) {
 
 /* ------------------------------------------------------------------ a-2.6 solver */
 /* cost / gradient / Hessian of one elliptic contact at residual x = jar (dim entries) */
-static double cone_eval(const ho_contact *con, const double *D, const double *x, double *g, double *H) {
-    int dim = con->dim; double mu = con->mu, U[6], N, T2 = 0, T;
+static real cone_eval(const ho_contact *con, const real *D, const real *x, real *g, real *H) {
+    int dim = con->dim; real mu = con->mu, U[6], N, T2 = 0, T;
     for (int j = 0; j < dim; j++) g[j] = 0;
-    if (H) memset(H, 0, sizeof(double)*36);
+    if (H) memset(H, 0, sizeof(real)*36);
     U[0] = x[0]*mu; N = U[0];
     for (int j = 1; j < dim; j++) { U[j] = x[j]*con->friction[j-1]; T2 += U[j]*U[j]; }
     T = sqrt(T2);
     if (N >= mu*T || (T <= 0 && N >= 0)) return 0;                                   /* top zone */
     if (mu*N + T <= 0 || (T <= 0 && N < 0)) {                                       /* bottom zone */
-        double c = 0;
+        real c = 0;
         for (int j = 0; j < dim; j++) { c += 0.5*D[j]*x[j]*x[j]; g[j] = D[j]*x[j]; if (H) H[6*j+j] = D[j]; }
         return c;
     }
-    double Dm = D[0] / (mu*mu*(1 + mu*mu)), NT = N - mu*T, gn[6];                     /* middle zone */
+    real Dm = D[0] / (mu*mu*(1 + mu*mu)), NT = N - mu*T, gn[6];                     /* middle zone */
     gn[0] = mu;
     for (int j = 1; j < dim; j++) gn[j] = -mu * U[j] * con->friction[j-1] / T;
     for (int j = 0; j < dim; j++) g[j] = Dm*NT*gn[j];
     if (H) {
         for (int j = 0; j < dim; j++) for (int k = 0; k < dim; k++) H[6*j+k] = Dm*gn[j]*gn[k];
         for (int j = 1; j < dim; j++) for (int k = 1; k < dim; k++) {
-            double fj = con->friction[j-1], fk = con->friction[k-1];
-            double h = -mu*fj*fk*((j == k ? 1.0/T : 0.0) - U[j]*U[k]/(T*T2));
+            real fj = con->friction[j-1], fk = con->friction[k-1];
+            real h = -mu*fj*fk*((j == k ? 1.0/T : 0.0) - U[j]*U[k]/(T*T2));
             H[6*j+k] += Dm*NT*h;
         }
     }
@@ -960,14 +988,14 @@ static double cone_eval(const ho_contact *con, const double *D, const double *x,
 }
 
 /* evaluate constraint cost at residual jar; optional gradient wrt jar (= -force) */
-static double constraint_cost(const ho_data *d, const double *jar, double *gout) {
-    double cost = 0;
+static real constraint_cost(const ho_data *d, const real *jar, real *gout) {
+    real cost = 0;
     for (int i = 0; i < d->nlimit_active; i++) {
         if (jar[i] < 0) { cost += 0.5*d->efc_D[i]*jar[i]*jar[i]; if (gout) gout[i] = d->efc_D[i]*jar[i]; }
         else if (gout) gout[i] = 0;
     }
     for (int c = 0; c < d->ncon; c++) {
-        const ho_contact *con = d->contact + c; int a = con->efc_address; double g[6];
+        const ho_contact *con = d->contact + c; int a = con->efc_address; real g[6];
         cost += cone_eval(con, d->efc_D + a, jar + a, g, NULL);
         if (gout) for (int j = 0; j < con->dim; j++) gout[a+j] = g[j];
     }
@@ -975,16 +1003,16 @@ static double constraint_cost(const ho_data *d, const double *jar, double *gout)
 }
 
 /* 1-D derivatives of the total cost along the search direction at step alpha */
-static void ls_eval(const ho_data *d, const double *jar, const double *jv, double alpha,
-                    double g1, double g2, double *dphi, double *ddphi) {
-    double dp = g1 + alpha*g2, hp = g2;
+static void ls_eval(const ho_data *d, const real *jar, const real *jv, real alpha,
+                    real g1, real g2, real *dphi, real *ddphi) {
+    real dp = g1 + alpha*g2, hp = g2;
     for (int i = 0; i < d->nlimit_active; i++) {
-        double x = jar[i] + alpha*jv[i];
+        real x = jar[i] + alpha*jv[i];
         if (x < 0) { dp += d->efc_D[i]*x*jv[i]; hp += d->efc_D[i]*jv[i]*jv[i]; }
     }
     for (int c = 0; c < d->ncon; c++) {
         const ho_contact *con = d->contact + c; int a = con->efc_address, dim = con->dim;
-        double x[6], g[6], H[36];
+        real x[6], g[6], H[36];
         for (int j = 0; j < dim; j++) x[j] = jar[a+j] + alpha*jv[a+j];
         cone_eval(con, d->efc_D + a, x, g, H);
         for (int j = 0; j < dim; j++) {
@@ -997,69 +1025,69 @@ static void ls_eval(const ho_data *d, const double *jar, const double *jv, doubl
 
 static void ho_solve(const ho_model *m, ho_data *d) {
     int nv = m->nv, ne = d->nefc;
-    double *qacc = d->qacc;
+    real *qacc = d->qacc;
     if (ne == 0) {
-        memcpy(qacc, d->qacc_smooth, sizeof(double)*(size_t)nv);
-        memset(d->qfrc_constraint, 0, sizeof(double)*(size_t)nv);
+        memcpy(qacc, d->qacc_smooth, sizeof(real)*(size_t)nv);
+        memset(d->qfrc_constraint, 0, sizeof(real)*(size_t)nv);
         d->solver_niter = 0; d->solver_cost = 0;
         return;
     }
-    static __thread double jar[NEFC_MAX], jv[NEFC_MAX], gr[NEFC_MAX];
-    double Ma[NV_MAX], grad[NV_MAX], search[NV_MAX], Mv[NV_MAX], H[NV_MAX*NV_MAX], Lh[NV_MAX*NV_MAX];
-    const double tol = m->opt[OPT_TOLERANCE], ls_tol = m->opt[OPT_LS_TOLERANCE];
+    static __thread real jar[NEFC_MAX], jv[NEFC_MAX], gr[NEFC_MAX];
+    real Ma[NV_MAX], grad[NV_MAX], search[NV_MAX], Mv[NV_MAX], H[NV_MAX*NV_MAX], Lh[NV_MAX*NV_MAX];
+    const real tol = m->opt[OPT_TOLERANCE], ls_tol = m->opt[OPT_LS_TOLERANCE];
     const int maxit = (int)m->opt[OPT_ITERATIONS], ls_maxit = (int)m->opt[OPT_LS_ITERATIONS];
-    const double scale = 1.0 / (m->opt[OPT_MEANINERTIA] * (nv > 1 ? nv : 1));
+    const real scale = 1.0 / (m->opt[OPT_MEANINERTIA] * (nv > 1 ? nv : 1));
 #define EVAL_AT(a, costvar) do { \
-        double gauss_ = 0; \
-        for (int i_ = 0; i_ < nv; i_++) { double s_ = 0; for (int k_ = 0; k_ < nv; k_++) s_ += d->M[i_*nv+k_]*(a)[k_]; Ma[i_] = s_; } \
+        real gauss_ = 0; \
+        for (int i_ = 0; i_ < nv; i_++) { real s_ = 0; for (int k_ = 0; k_ < nv; k_++) s_ += d->M[i_*nv+k_]*(a)[k_]; Ma[i_] = s_; } \
         for (int i_ = 0; i_ < nv; i_++) gauss_ += 0.5*((a)[i_] - d->qacc_smooth[i_])*(Ma[i_] - d->qfrc_smooth[i_]); \
-        for (int i_ = 0; i_ < ne; i_++) { double s_ = -d->efc_aref[i_]; const double *r_ = d->efc_J + (size_t)i_*nv; \
+        for (int i_ = 0; i_ < ne; i_++) { real s_ = -d->efc_aref[i_]; const real *r_ = d->efc_J + (size_t)i_*nv; \
             for (int k_ = 0; k_ < nv; k_++) s_ += r_[k_]*(a)[k_]; jar[i_] = s_; } \
         costvar = gauss_ + constraint_cost(d, jar, gr); } while (0)
     /* warm start: the cheaper of qacc_warmstart and qacc_smooth */
-    double cost_w, cost_s, cost;
+    real cost_w, cost_s, cost;
     EVAL_AT(d->qacc_warmstart, cost_w);
     EVAL_AT(d->qacc_smooth, cost_s);
-    if (cost_w < cost_s) { memcpy(qacc, d->qacc_warmstart, sizeof(double)*(size_t)nv); EVAL_AT(qacc, cost); }
-    else { memcpy(qacc, d->qacc_smooth, sizeof(double)*(size_t)nv); cost = cost_s; }
+    if (cost_w < cost_s) { memcpy(qacc, d->qacc_warmstart, sizeof(real)*(size_t)nv); EVAL_AT(qacc, cost); }
+    else { memcpy(qacc, d->qacc_smooth, sizeof(real)*(size_t)nv); cost = cost_s; }
     int iter = 0;
     d->solver_ntrace = 0; d->solver_ls_max = 0; d->solver_refused = 0;
     d->solver_trace[d->solver_ntrace++] = cost;
     for (; iter < maxit; iter++) {
         /* gradient and Hessian */
         for (int i = 0; i < nv; i++) {
-            double s = Ma[i] - d->qfrc_smooth[i];
+            real s = Ma[i] - d->qfrc_smooth[i];
             for (int r = 0; r < ne; r++) s += d->efc_J[(size_t)r*nv+i]*gr[r];
             grad[i] = s;
         }
-        memcpy(H, d->M, sizeof(double)*(size_t)nv*(size_t)nv);
+        memcpy(H, d->M, sizeof(real)*(size_t)nv*(size_t)nv);
         for (int r = 0; r < d->nlimit_active; r++) if (jar[r] < 0) {
-            const double *row = d->efc_J + (size_t)r*nv;
+            const real *row = d->efc_J + (size_t)r*nv;
             for (int i = 0; i < nv; i++) if (row[i] != 0) for (int k = 0; k < nv; k++) H[i*nv+k] += d->efc_D[r]*row[i]*row[k];
         }
         for (int c = 0; c < d->ncon; c++) {
             const ho_contact *con = d->contact + c; int a = con->efc_address, dim = con->dim;
-            double g[6], Hc[36];
+            real g[6], Hc[36];
             cone_eval(con, d->efc_D + a, jar + a, g, Hc);
             for (int j = 0; j < dim; j++) for (int k2 = 0; k2 < dim; k2++) {
-                double h = Hc[6*j+k2]; if (h == 0) continue;
-                const double *rj = d->efc_J + (size_t)(a+j)*nv, *rk = d->efc_J + (size_t)(a+k2)*nv;
+                real h = Hc[6*j+k2]; if (h == 0) continue;
+                const real *rj = d->efc_J + (size_t)(a+j)*nv, *rk = d->efc_J + (size_t)(a+k2)*nv;
                 for (int i = 0; i < nv; i++) if (rj[i] != 0) for (int k = 0; k < nv; k++) H[i*nv+k] += h*rj[i]*rk[k];
             }
         }
         if (cholesky(Lh, H, nv) != 0) { d->bad = 1; break; }
-        double gnorm = 0;
+        real gnorm = 0;
         for (int i = 0; i < nv; i++) { search[i] = -grad[i]; gnorm += grad[i]*grad[i]; }
         gnorm = sqrt(gnorm);
         if (scale*gnorm < tol) break;
         chol_solve(Lh, nv, search);
         /* exact line search along `search` (safeguarded 1-D Newton on phi') */
-        double g1 = 0, g2 = 0, snorm = 0;
-        for (int i = 0; i < nv; i++) { double s = 0; for (int k = 0; k < nv; k++) s += d->M[i*nv+k]*search[k]; Mv[i] = s; }
+        real g1 = 0, g2 = 0, snorm = 0;
+        for (int i = 0; i < nv; i++) { real s = 0; for (int k = 0; k < nv; k++) s += d->M[i*nv+k]*search[k]; Mv[i] = s; }
         for (int i = 0; i < nv; i++) { g1 += search[i]*(Ma[i] - d->qfrc_smooth[i]); g2 += search[i]*Mv[i]; snorm += search[i]*search[i]; }
         snorm = sqrt(snorm);
-        for (int r = 0; r < ne; r++) { double s = 0; const double *row = d->efc_J + (size_t)r*nv; for (int k = 0; k < nv; k++) s += row[k]*search[k]; jv[r] = s; }
-        double gtol = tol * ls_tol * snorm / scale, dp, hp, alpha, lo = 0, hi = -1;
+        for (int r = 0; r < ne; r++) { real s = 0; const real *row = d->efc_J + (size_t)r*nv; for (int k = 0; k < nv; k++) s += row[k]*search[k]; jv[r] = s; }
+        real gtol = tol * ls_tol * snorm / scale, dp, hp, alpha, lo = 0, hi = -1;
         ls_eval(d, jar, jv, 0.0, g1, g2, &dp, &hp);
         if (dp >= 0 || hp <= 0) break;
         alpha = -dp / hp;
@@ -1072,14 +1100,14 @@ static void ho_solve(const ho_model *m, ho_data *d) {
             if (it + 1 > d->solver_ls_max) d->solver_ls_max = it + 1;
             if (fabs(dp) < gtol) break;
             if (dp < 0) lo = alpha; else hi = alpha;
-            double nxt = alpha - dp / hp;
+            real nxt = alpha - dp / hp;
             if (!(nxt > lo) || (hi > 0 && !(nxt < hi))) nxt = hi > 0 ? 0.5*(lo + hi) : 2*alpha;
             else if (it >= 5 && (it & 1) && hi > 0) nxt = 0.5*(lo + hi);
             alpha = nxt;
         }
         if (alpha <= 0) break;
         for (int i = 0; i < nv; i++) qacc[i] += alpha*search[i];
-        double oldcost = cost;
+        real oldcost = cost;
         EVAL_AT(qacc, cost);
         if (cost > oldcost) {          /* a step that raises the cost is never taken (MuJoCo's search returns a point no worse than alpha = 0) */
             for (int i = 0; i < nv; i++) qacc[i] -= alpha*search[i];
@@ -1092,7 +1120,7 @@ static void ho_solve(const ho_model *m, ho_data *d) {
     }
     d->solver_niter = iter; d->solver_cost = cost;
     for (int r = 0; r < ne; r++) d->efc_force[r] = -gr[r];
-    for (int i = 0; i < nv; i++) { double s = 0; for (int r = 0; r < ne; r++) s += d->efc_J[(size_t)r*nv+i]*d->efc_force[r]; d->qfrc_constraint[i] = s; }
+    for (int i = 0; i < nv; i++) { real s = 0; for (int r = 0; r < ne; r++) s += d->efc_J[(size_t)r*nv+i]*d->efc_force[r]; d->qfrc_constraint[i] = s; }
 #undef EVAL_AT
 }
 
@@ -1108,22 +1136,22 @@ void ho_forward(const ho_model *m, ho_data *d) {
 
 /* a-2.7 mj_Euler: implicit joint damping, semi-implicit position update */
 static void ho_euler(const ho_model *m, ho_data *d) {
-    int nv = m->nv; double h = m->opt[OPT_TIMESTEP];
-    double qacc[NV_MAX], A[NV_MAX*NV_MAX], La[NV_MAX*NV_MAX];
+    int nv = m->nv; real h = m->opt[OPT_TIMESTEP];
+    real qacc[NV_MAX], A[NV_MAX*NV_MAX], La[NV_MAX*NV_MAX];
     int damped = 0;
     for (int k = 0; k < nv; k++) if (m->dof_damping[k] > 0) damped = 1;
     if (damped) {
-        memcpy(A, d->M, sizeof(double)*(size_t)nv*(size_t)nv);
+        memcpy(A, d->M, sizeof(real)*(size_t)nv*(size_t)nv);
         /* MuJoCo: (M + h B) a = qfrc_smooth + qfrc_constraint.  With the option the right-hand side is M qacc - the same vector at the
          * solver's fixed point (its gradient vanishes there), what the HIP path integrates (deviations): the parity tests
          * report the difference from both forms */
         for (int k = 0; k < nv; k++) {
             A[k*nv+k] += h*m->dof_damping[k];
-            if (d->euler_rhs_macc) { double t = 0; for (int j = 0; j < nv; j++) t += d->M[k*nv+j]*d->qacc[j]; qacc[k] = t; }
+            if (d->euler_rhs_macc) { real t = 0; for (int j = 0; j < nv; j++) t += d->M[k*nv+j]*d->qacc[j]; qacc[k] = t; }
             else qacc[k] = d->qfrc_smooth[k] + d->qfrc_constraint[k];
         }
         if (cholesky(La, A, nv) == 0) chol_solve(La, nv, qacc); else d->bad = 1;
-    } else memcpy(qacc, d->qacc, sizeof(double)*(size_t)nv);
+    } else memcpy(qacc, d->qacc, sizeof(real)*(size_t)nv);
     for (int k = 0; k < nv; k++) d->qvel[k] += h*qacc[k];
     for (int l = 1; l < m->nlink; l++) {
         int d0 = m->link_dofadr[l];
@@ -1131,10 +1159,10 @@ static void ho_euler(const ho_model *m, ho_data *d) {
             int a = m->link_qposadr[l];
             for (int k = 0; k < 3; k++) d->qpos[a+k] += h*d->qvel[d0+k];
             /* mju_quatIntegrate: rotate by |w| h about w (local frame) */
-            double w[3] = { d->qvel[d0+3], d->qvel[d0+4], d->qvel[d0+5] }, ang = norm3(w)*h;
+            real w[3] = { d->qvel[d0+3], d->qvel[d0+4], d->qvel[d0+5] }, ang = norm3(w)*h;
             if (ang > 0) {
-                double ax[3]; copy3(ax, w); normalize3(ax);
-                double s = sin(0.5*ang), qr[4] = { cos(0.5*ang), ax[0]*s, ax[1]*s, ax[2]*s }, qn[4];
+                real ax[3]; copy3(ax, w); normalize3(ax);
+                real s = sin(0.5*ang), qr[4] = { cos(0.5*ang), ax[0]*s, ax[1]*s, ax[2]*s }, qn[4];
                 quatmul(qn, d->qpos + a + 3, qr); quatnorm(qn);
                 memcpy(d->qpos + a + 3, qn, sizeof qn);
             }
@@ -1142,7 +1170,7 @@ static void ho_euler(const ho_model *m, ho_data *d) {
             for (int k = d0; k < d0 + m->link_dofnum[l]; k++) d->qpos[m->dof_qposadr[k]] += h*d->qvel[k];
         }
     }
-    memcpy(d->qacc_warmstart, d->qacc, sizeof(double)*(size_t)nv);
+    memcpy(d->qacc_warmstart, d->qacc, sizeof(real)*(size_t)nv);
     d->time += h;
 }
 
@@ -1159,9 +1187,9 @@ void ho_step(const ho_model *m, ho_data *d) {
 }
 
 /* world position of an (original, pre-folding) body; mocap bodies read mocap_pos */
-void ho_body_xpos(const ho_model *m, const ho_data *d, int body, double *out) {
+void ho_body_xpos(const ho_model *m, const ho_data *d, int body, real *out) {
     if (m->body_mocap[body]) { copy3(out, d->mocap_pos); return; }
-    int l = m->body_link[body]; double t[3];
+    int l = m->body_link[body]; real t[3];
     mulmv3(t, d->xmat + 9*l, m->body_pos + 3*body); add3(out, d->xpos + 3*l, t);
 }
 
@@ -1169,15 +1197,15 @@ void ho_body_xpos(const ho_model *m, const ho_data *d, int body, double *out) {
  * break on success.  goal_body < 0 means `goals is None` (done stays False).  xpos is the one
  * computed by the substep's forward pass (i.e. at the pre-integration qpos), exactly what
  * sim.data.get_body_xpos returns after sim.step().  Returns substeps executed; *done set. */
-int ho_env_step(const ho_model *m, ho_data *d, const double *ctrl, int nsub, int goal_body,
-                const double *goal, double geofence, int *done) {
-    memcpy(d->ctrl, ctrl, sizeof(double)*(size_t)m->nu);
+int ho_env_step(const ho_model *m, ho_data *d, const real *ctrl, int nsub, int goal_body,
+                const real *goal, real geofence, int *done) {
+    memcpy(d->ctrl, ctrl, sizeof(real)*(size_t)m->nu);
     *done = 0;
     int i = 0;
     for (; i < nsub; i++) {
         ho_step(m, d);
         if (goal_body >= 0) {
-            double p[3], r[3]; ho_body_xpos(m, d, goal_body, p); sub3(r, p, goal);
+            real p[3], r[3]; ho_body_xpos(m, d, goal_body, p); sub3(r, p, goal);
             if (sqrt(dot3(r, r)) < geofence) { *done = 1; i++; break; }
         }
     }
@@ -1185,26 +1213,26 @@ int ho_env_step(const ho_model *m, ho_data *d, const double *ctrl, int nsub, int
 }
 
 /* ---- accessors for ctypes */
-double *ho_qpos(ho_data *d) { return d->qpos; }
-double *ho_qvel(ho_data *d) { return d->qvel; }
-double *ho_ctrl(ho_data *d) { return d->ctrl; }
-double *ho_qacc(ho_data *d) { return d->qacc; }
-double *ho_qacc_warmstart(ho_data *d) { return d->qacc_warmstart; }
-double *ho_qacc_smooth(ho_data *d) { return d->qacc_smooth; }
-double *ho_qfrc_smooth(ho_data *d) { return d->qfrc_smooth; }
-double *ho_qfrc_bias(ho_data *d) { return d->qfrc_bias; }
-double *ho_qfrc_constraint(ho_data *d) { return d->qfrc_constraint; }
-double *ho_mocap_pos(ho_data *d) { return d->mocap_pos; }
-double *ho_xpos(ho_data *d) { return d->xpos; }
-double *ho_xquat(ho_data *d) { return d->xquat; }
-double *ho_xmat(ho_data *d) { return d->xmat; }
-double *ho_M(ho_data *d) { return d->M; }
-double *ho_efc_J(ho_data *d) { return d->efc_J; }
-double *ho_efc_force(ho_data *d) { return d->efc_force; }
-double *ho_efc_aref(ho_data *d) { return d->efc_aref; }
-double *ho_efc_R(ho_data *d) { return d->efc_R; }
-double *ho_efc_pos(ho_data *d) { return d->efc_pos; }
-double *ho_time(ho_data *d) { return &d->time; }
+real *ho_qpos(ho_data *d) { return d->qpos; }
+real *ho_qvel(ho_data *d) { return d->qvel; }
+real *ho_ctrl(ho_data *d) { return d->ctrl; }
+real *ho_qacc(ho_data *d) { return d->qacc; }
+real *ho_qacc_warmstart(ho_data *d) { return d->qacc_warmstart; }
+real *ho_qacc_smooth(ho_data *d) { return d->qacc_smooth; }
+real *ho_qfrc_smooth(ho_data *d) { return d->qfrc_smooth; }
+real *ho_qfrc_bias(ho_data *d) { return d->qfrc_bias; }
+real *ho_qfrc_constraint(ho_data *d) { return d->qfrc_constraint; }
+real *ho_mocap_pos(ho_data *d) { return d->mocap_pos; }
+real *ho_xpos(ho_data *d) { return d->xpos; }
+real *ho_xquat(ho_data *d) { return d->xquat; }
+real *ho_xmat(ho_data *d) { return d->xmat; }
+real *ho_M(ho_data *d) { return d->M; }
+real *ho_efc_J(ho_data *d) { return d->efc_J; }
+real *ho_efc_force(ho_data *d) { return d->efc_force; }
+real *ho_efc_aref(ho_data *d) { return d->efc_aref; }
+real *ho_efc_R(ho_data *d) { return d->efc_R; }
+real *ho_efc_pos(ho_data *d) { return d->efc_pos; }
+real *ho_time(ho_data *d) { return &d->time; }
 int ho_ncon(const ho_data *d) { return d->ncon; }
 int ho_nefc(const ho_data *d) { return d->nefc; }
 int ho_bad(const ho_data *d) { return d->bad; }
@@ -1213,38 +1241,38 @@ void ho_set_euler_rhs(ho_data *d, int m_qacc) { d->euler_rhs_macc = m_qacc != 0;
 /* solver introspection (tests only): which = 0 number of trace entries, 1 largest line-search evaluation count of an iteration, 2 a cost-raising step was refused,
  * 3 number of active limit rows (they precede the contact rows) */
 int ho_solver_stat(const ho_data *d, int which) { return which == 0 ? d->solver_ntrace : which == 1 ? d->solver_ls_max : which == 2 ? d->solver_refused : d->nlimit_active; }
-double *ho_solver_trace(ho_data *d) { return d->solver_trace; }
+real *ho_solver_trace(ho_data *d) { return d->solver_trace; }
 /* contact i -> out[0:5] friction, [5] first constraint row */
-void ho_contact_get2(const ho_data *d, int i, double *out) {
+void ho_contact_get2(const ho_data *d, int i, real *out) {
     const ho_contact *c = d->contact + i;
-    memcpy(out, c->friction, 5*sizeof(double)); out[5] = c->efc_address;
+    memcpy(out, c->friction, 5*sizeof(real)); out[5] = c->efc_address;
 }
 /* contact i -> out[0:3] pos, [3:12] frame, [12] dist, [13] geom1, [14] geom2, [15] dim, [16] mu */
-void ho_contact_get(const ho_data *d, int i, double *out) {
+void ho_contact_get(const ho_data *d, int i, real *out) {
     const ho_contact *c = d->contact + i;
-    copy3(out, c->pos); memcpy(out + 3, c->frame, 9*sizeof(double)); out[12] = c->dist;
+    copy3(out, c->pos); memcpy(out + 3, c->frame, 9*sizeof(real)); out[12] = c->dist;
     out[13] = c->geom1; out[14] = c->geom2; out[15] = c->dim; out[16] = c->mu;
 }
 
 /* ---- batched env-step for the cpu_baseline leg: n independent envs, OpenMP over envs.
  * state arrays are [n, nq] / [n, nv] / [n, nu] row-major fp64 and are updated in place. */
-int ho_batch_env_step(const ho_model *m, int n, double *qpos, double *qvel, double *warm, const double *ctrl,
-                      const double *mocap, int nsub, int goal_body, double geofence, int *done, int nthreads) {
+int ho_batch_env_step(const ho_model *m, int n, real *qpos, real *qvel, real *warm, const real *ctrl,
+                      const real *mocap, int nsub, int goal_body, real geofence, int *done, int nthreads) {
     int total = 0;
 #pragma omp parallel for num_threads(nthreads) reduction(+:total) schedule(dynamic, 1)
     for (int e = 0; e < n; e++) {
         ho_data *d = ho_data_new(m);
         ho_reset(m, d);
-        memcpy(d->qpos, qpos + (size_t)e*m->nq, sizeof(double)*(size_t)m->nq);
-        memcpy(d->qvel, qvel + (size_t)e*m->nv, sizeof(double)*(size_t)m->nv);
-        memcpy(d->qacc_warmstart, warm + (size_t)e*m->nv, sizeof(double)*(size_t)m->nv);
+        memcpy(d->qpos, qpos + (size_t)e*m->nq, sizeof(real)*(size_t)m->nq);
+        memcpy(d->qvel, qvel + (size_t)e*m->nv, sizeof(real)*(size_t)m->nv);
+        memcpy(d->qacc_warmstart, warm + (size_t)e*m->nv, sizeof(real)*(size_t)m->nv);
         copy3(d->mocap_pos, mocap + 3*(size_t)e);
         int dn = 0;
         total += ho_env_step(m, d, ctrl + (size_t)e*m->nu, nsub, goal_body, mocap + 3*(size_t)e, geofence, &dn);
         done[e] = dn;
-        memcpy(qpos + (size_t)e*m->nq, d->qpos, sizeof(double)*(size_t)m->nq);
-        memcpy(qvel + (size_t)e*m->nv, d->qvel, sizeof(double)*(size_t)m->nv);
-        memcpy(warm + (size_t)e*m->nv, d->qacc_warmstart, sizeof(double)*(size_t)m->nv);
+        memcpy(qpos + (size_t)e*m->nq, d->qpos, sizeof(real)*(size_t)m->nq);
+        memcpy(qvel + (size_t)e*m->nv, d->qvel, sizeof(real)*(size_t)m->nv);
+        memcpy(warm + (size_t)e*m->nv, d->qacc_warmstart, sizeof(real)*(size_t)m->nv);
         ho_data_free(d);
     }
     return total;

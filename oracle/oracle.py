@@ -13,22 +13,24 @@ from pathlib import Path
 import numpy as np
 
 _HERE = Path(__file__).parent
-_LIB = None
+_LIBS = {}
+_REAL = {"f64": ("libhsr_oracle.so", C.c_double, np.float64), "f32": ("libhsr_oracle_f32.so", C.c_float, np.float32)}
 
 
-def build(force: bool = False) -> Path:
-    so = _HERE / "libhsr_oracle.so"
+def build(force: bool = False, real: str = "f64") -> Path:
+    so = _HERE / _REAL[real][0]
     src = _HERE / "hsr_oracle.c"
     if force or not so.exists() or so.stat().st_mtime < src.stat().st_mtime:
-        subprocess.check_call(["make", "-C", str(_HERE), "libhsr_oracle.so"], stdout=subprocess.DEVNULL)
+        subprocess.check_call(["make", "-C", str(_HERE), so.name], stdout=subprocess.DEVNULL)
     return so
 
 
-def lib():
-    global _LIB
-    if _LIB is None:
-        L = C.CDLL(str(build()))
-        vp, dp, ip = C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int)
+def lib(real: str = "f64"):
+    """real = "f32": the same restatement compiled with -DHO_REAL=float (what single precision alone does to a result; tests only)."""
+    if real not in _LIBS:
+        L = C.CDLL(str(build(real=real)))
+        assert L.ho_real_bytes() == (8 if real == "f64" else 4)
+        vp, dp, ip = C.c_void_p, C.POINTER(_REAL[real][1]), C.POINTER(C.c_int)
         L.ho_model_load.restype = vp; L.ho_model_load.argtypes = [C.c_char_p, C.c_size_t]
         L.ho_model_free.argtypes = [vp]
         L.ho_model_size.restype = C.c_int; L.ho_model_size.argtypes = [vp, C.c_int]
@@ -38,7 +40,7 @@ def lib():
             getattr(L, f).argtypes = [vp, vp]; getattr(L, f).restype = None
         L.ho_body_xpos.argtypes = [vp, vp, C.c_int, dp]
         L.ho_env_step.restype = C.c_int
-        L.ho_env_step.argtypes = [vp, vp, dp, C.c_int, C.c_int, dp, C.c_double, ip]
+        L.ho_env_step.argtypes = [vp, vp, dp, C.c_int, C.c_int, dp, _REAL[real][1], ip]
         for f in ("qpos", "qvel", "ctrl", "qacc", "qacc_warmstart", "qacc_smooth", "qfrc_smooth",
                   "qfrc_bias", "qfrc_constraint", "mocap_pos", "xpos", "xquat", "xmat", "M", "efc_J",
                   "efc_force", "efc_aref", "efc_R", "efc_pos", "time"):
@@ -51,22 +53,23 @@ def lib():
         L.ho_solver_trace.restype = dp; L.ho_solver_trace.argtypes = [vp]
         L.ho_set_euler_rhs.argtypes = [vp, C.c_int]; L.ho_set_euler_rhs.restype = None
         L.ho_batch_env_step.restype = C.c_int
-        L.ho_batch_env_step.argtypes = [vp, C.c_int, dp, dp, dp, dp, dp, C.c_int, C.c_int, C.c_double, ip, C.c_int]
-        _LIB = L
-    return _LIB
+        L.ho_batch_env_step.argtypes = [vp, C.c_int, dp, dp, dp, dp, dp, C.c_int, C.c_int, _REAL[real][1], ip, C.c_int]
+        _LIBS[real] = L
+    return _LIBS[real]
 
 
 def _dp(a):
-    return a.ctypes.data_as(C.POINTER(C.c_double))
+    return a.ctypes.data_as(C.POINTER(C.c_double if a.dtype == np.float64 else C.c_float))
 
 
 class OracleSim:
     """One fp64 environment; mirrors the slice of mujoco_py.MjSim the reference touches
     (hsr/mujoco_env.py:33-34,84,90-94,101-103; hsr/env.py:116,123,169,175-176)."""
 
-    def __init__(self, model):
+    def __init__(self, model, real: str = "f64"):
         self.model = model
-        self._L = lib()
+        self._dtype = _REAL[real][2]
+        self._L = lib(real)
         raw = model.to_bytes()
         self._m = self._L.ho_model_load(raw, len(raw))
         assert self._m, "oracle failed to load model blob"
@@ -116,7 +119,7 @@ class OracleSim:
     def solver_niter(self): return self._L.ho_solver_niter(self._d)
 
     def contacts(self):
-        out = np.zeros((self.ncon, 17))
+        out = np.zeros((self.ncon, 17), self._dtype)
         for i in range(self.ncon):
             self._L.ho_contact_get(self._d, i, _dp(out[i]))
         return out
@@ -124,7 +127,7 @@ class OracleSim:
     def contact_cones(self):
         """Per contact: (first constraint row, dim, mu, friction[5]) - what a cost function needs besides efc()."""
         out = []
-        a, b = np.zeros(17), np.zeros(6)
+        a, b = np.zeros(17, self._dtype), np.zeros(6, self._dtype)
         for i in range(self.ncon):
             self._L.ho_contact_get(self._d, i, _dp(a)); self._L.ho_contact_get2(self._d, i, _dp(b))
             out.append((int(b[5]), int(a[15]), float(a[16]), b[:5].copy()))
@@ -145,13 +148,13 @@ class OracleSim:
                     R=g("efc_R", (512,))[:ne], pos=g("efc_pos", (512,))[:ne])
 
     def body_xpos(self, body_id: int):
-        out = np.zeros(3)
+        out = np.zeros(3, self._dtype)
         self._L.ho_body_xpos(self._m, self._d, int(body_id), _dp(out))
         return out
 
     def env_step(self, ctrl, nsub, goal_body=-1, goal=None, geofence=0.0):
-        ctrl = np.ascontiguousarray(ctrl, dtype=np.float64)
-        goal = np.zeros(3) if goal is None else np.ascontiguousarray(goal, dtype=np.float64)
+        ctrl = np.ascontiguousarray(ctrl, dtype=self._dtype)
+        goal = np.zeros(3, self._dtype) if goal is None else np.ascontiguousarray(goal, dtype=self._dtype)
         done = C.c_int(0)
         n = self._L.ho_env_step(self._m, self._d, _dp(ctrl), int(nsub), int(goal_body), _dp(goal),
                                 float(geofence), C.byref(done))

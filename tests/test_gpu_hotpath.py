@@ -157,8 +157,8 @@ def test_sparse_factorisation_equals_the_dense_one(models):
     """cfg4 (robot + three blocks): in an env whose contacts couple at most one block to the robot and no block to another - 99 % of the env-substeps, 95 % of those of
     the hardest tasks - the Newton Hessian is factored with the robot's seven dense steps and then dof t of every block at once (solve_g.h chol_sparse_fwd / chol_sparse_back:
     13 dependent steps and ~400 instructions instead of 25 and ~650); test hook 128 keeps the dense factorisation.  Three batches - blocks apart (the robot touches none or
-    one), a finger pushed into a block (one block coupled to the robot), two blocks pushed into each other (dense fallback, decided per env: next to envs of the same wave
-    that take the sparse path) - one substep and then twenty more: both paths must agree BIT FOR BIT (same arithmetic on the entries that are not structurally zero); the
+    one), a finger pushed into a block (one block coupled to the robot), two blocks pushed into each other (dense fallback; the choice is made per WAVE - legal because the two paths are bit-identical - so such an env also
+    sends its wave neighbours down the dense path) - one substep and then twenty more: both paths must agree BIT FOR BIT (same arithmetic on the entries that are not structurally zero); the
     single substep of the first batch must follow the oracle like every other single-substep test."""
     m = models["cfg4"]
     n = 128
@@ -196,6 +196,8 @@ def test_sparse_factorisation_equals_the_dense_one(models):
         # the sparse path performs the dense path's arithmetic on the structurally non-zero entries in the same order: BIT-IDENTICAL results - which is what allows the
         # choice to be made per wave (an env's result must never depend on its neighbours)
         assert dv.max() == 0.0 and dm.max() == 0.0 and (ta == tb).all(), (dv.max(), dm.max())
+        # ... to the BIT (round-5 advisor: a difference of 0.0 hides -0 against +0 - the dense path adds -0 * x terms that the merged one skips)
+        assert np.array_equal(a1_.view(np.uint32), b1_.view(np.uint32)) and np.array_equal(am.view(np.uint32), bm.view(np.uint32))
         if tag == "apart":
             unexplained = []
             for e in range(n):
@@ -838,6 +840,69 @@ def test_pinched_block_contacts_follow_the_oracle(models, warm):
     sim.close()
 
 
+def test_pinch_allowance_is_precision(models):
+    """is the allowance of test_pinched_block_contacts_follow_the_oracle single precision, or a defect?  The same states,
+    cold start (no portal carried over), first checkpoint: the HIP contacts against the fp64 oracle AND against the same oracle compiled in single
+    precision (oracle/Makefile: libhsr_oracle_f32.so, -DHO_REAL=float; test infrastructure), plus the two oracles against each other - no kernel
+    involved.  If ending on another portal triangle in fp32 is what separates kernel and fp64 oracle, the fp32 oracle has to (a) disagree with
+    the fp64 one in about as many envs, and (b) the kernel must not be further from the fp64 oracle than the fp32 oracle is."""
+    m = models["cfg3"]
+    n = 96
+    rng = np.random.default_rng(3)
+    q, v, ctrl = random_states(m, n, rng)
+    bl, br = m.body_id("hand_l_distal_link"), m.body_id("hand_r_distal_link")
+    a = m.free_joint_qadrs()[0]
+    for e in range(n):
+        o = OracleSim(m); o.qpos[:] = q[e]; o.forward()
+        q[e, a:a + 3] = 0.5 * (o.body_xpos(bl) + o.body_xpos(br)) + rng.uniform(-0.01, 0.01, 3)
+        quat = rng.normal(size=4); q[e, a + 3:a + 7] = quat / np.linalg.norm(quat)
+    v[:] = 0
+    sim = hs.BatchSim(m, n)
+    sim.set_mpr_warm(False)
+    sim.set_debug(True)
+    sim.set_state(np.zeros(n), q, v)
+    sim.step(ctrl, 1)
+    t1, q1, v1 = sim.get_state()
+    qs, vs = q1.astype(np.float64), v1.astype(np.float64)
+    sim.step(ctrl, 1)
+    con = sim.get_field(hs.F_CONTACT)
+    sim.close()
+
+    def as_slots(oc):          # an oracle contact list in the layout contact_mismatch expects of the HIP path
+        slots = np.zeros((m.nslot, 7)); slots[:, 6] = 1.0
+        for p in range(m.npair):
+            rows = oc[(oc[:, 13] == m.pair_geom1[p]) & (oc[:, 14] == m.pair_geom2[p])] if len(oc) else oc
+            for i, r in enumerate(rows[:int(m.pair_slot[p + 1]) - int(m.pair_slot[p])]):
+                slots[int(m.pair_slot[p]) + i] = np.r_[r[0:3], r[3:6], r[12]]
+        return slots
+
+    hip64, hip32, o32_64 = [], [], []
+    for e in range(n):
+        lists = []
+        for real in ("f64", "f32"):
+            o = OracleSim(m, real)
+            o.qpos[:] = qs[e]; o.qvel[:] = vs[e]; o.ctrl[:] = ctrl[e]
+            o.forward()
+            lists.append(o.contacts().astype(np.float64))
+        for out, why in ((hip64, contact_mismatch(m, con[e], lists[0])), (hip32, contact_mismatch(m, con[e], lists[1])),
+                         (o32_64, contact_mismatch(m, as_slots(lists[1]), lists[0]))):
+            if why is not None:
+                out.append((e, why))
+    print(f"pinch, cold start, first checkpoint, envs beyond the stage tolerances: HIP vs fp64 oracle {len(hip64)}, HIP vs fp32 oracle {len(hip32)}, "
+          f"fp32 oracle vs fp64 oracle {len(o32_64)} of {n}\n  HIP/fp64 {hip64}\n  HIP/fp32 {hip32}\n  fp32/fp64 {o32_64}")
+    # Measured (round 6): HIP vs fp64 oracle 13 envs, fp32 oracle vs fp64 oracle 13 - eleven of them the SAME envs with the same differences to
+    # three digits (depth 2.3e-5 ... 6.2e-4, normal up to 3e-2: another triangle of the same face) -, HIP vs fp32 oracle 4 (depth 1.2e-5 ... 8.9e-5:
+    # two are the fp32 oracle's own, two the kernel's, whose depth is measured along the portal normal instead of libccd's expanded quadratic).
+    # The allowance of the fp64 comparison is what single precision does to libccd's MPR in this regime, not a defect of the kernels.
+    s64, s32 = {e for e, _ in hip64}, {e for e, _ in o32_64}
+    assert len(hip32) <= 6 and len(hip32) < len(hip64), (hip32, hip64)
+    assert len(s64 - s32) <= 3, ("envs in which the kernel, but not the fp32 oracle, leaves the fp64 oracle", sorted(s64 - s32))
+    assert len(o32_64) >= len(hip64) - 3
+    for e, why in hip32:
+        kind, size = why.split()[0], float(why.split()[1])
+        assert kind in ("depth", "normal", "position") and size < {"depth": 2e-4, "normal": 2e-2, "position": 2e-3}[kind], (e, why)
+
+
 def test_pinch_warm_start_against_cold_start_at_the_same_state(models):
     """Round-3 advisor: the pinch test bounds each mode against the oracle, so a regression of the warm start of the size of its allowance
     would pass.  Here the two modes meet directly: the warm-started batch runs on (1, 8, 20 substeps, caches carried), a second batch
@@ -981,11 +1046,12 @@ def test_work_queue_watchdog_flag_is_sticky(models):
     sim.close()
 
 
-@pytest.mark.parametrize("cfg,n", [("cfg1", 1), ("cfg2", 4096), ("cfg3", 8192), ("cfg4", 8192), ("cfg4", 32768), ("cupboard", 8192)])
+@pytest.mark.parametrize("cfg,n", [("cfg1", 1), ("cfg2", 4096), ("cfg3", 8192), ("cfg4", 8192), ("cfg4", 32768), ("cfg4", 65536), ("cupboard", 8192)])
 def test_full_size_invariants(models, cfg, n):
     """BASELINE configs 1-3 at their OWN sizes (1 env; 4096 envs x 1 block, slides only; 8192 envs, all DOFs), the per-GPU shard of configs 4 / 5 (8192 envs x 3
     blocks: 4096 two-env tasks through the work queue, the 32-env replay without it), config 4's TOTAL size on one GPU (32768 envs x 3 blocks: 16384 tasks through
-    the queue - what its four shards compute, env for env, since an env's result does not depend on the batch it runs in) and the cupboard scene, on the bench's inputs, two
+    the queue - what its four shards compute, env for env, since an env's result does not depend on the batch it runs in), config 5's TOTAL size likewise (65536 envs x 3
+    blocks, 32768 tasks through the queue: what its eight shards compute) and the cupboard scene, on the bench's inputs, two
     env-steps of 300 substeps with the goal test and the reset of finished envs in between, through properties that do not depend on the
     size: every env finite and unflagged, unit quaternions, blocks between floor and ceiling, reward == done and every finished env really
     inside the geofence, 300 substeps run unless finished; the run is deterministic (a second batch on the same inputs is bit-identical); envs
@@ -1265,13 +1331,13 @@ def test_solver_optimum_on_hard_states(models):
     constraint cost - found by scipy on a numpy restatement of the cost (tests/test_oracle_optimality.py: neither the oracle's cone routines nor its
     Newton solver are involved; the oracle only supplies M, J, aref, R of its forward pass at the same state).  States whose fp32 contact list differs
     from the fp64 one beyond the stage tolerances pose a different problem and are set aside (counted, bounded).  fp32 bounds: the scaled cost of the
-    HIP solution lies within 1e-6 (1 + |scaled cost|) of the minimum (measured: median 9e-10, worst 3.8e-8; fp32 resolves the cost itself to 6e-8 of its value), |qacc - a*| < 2e-2 + 2e-3 |a*| per dof in 95 % of the states (the tolerance of the substep test)."""
+    HIP solution lies within 1e-6 (1 + |scaled cost|) of the minimum (measured: median 9e-10, worst 3.8e-8; fp32 resolves the cost itself to 6e-8 of its value), |qacc - a*| < 1.1 (2e-2 + 2e-3 |a*|) per dof in EVERY kept state (measured worst 0.98), at most 5 % of the states set aside (measured 8 of 250), at least 30 three-block states kept; formerly: in 95 % of the states (the tolerance of the substep test)."""
     import test_oracle_optimality as too
     rows = list(too.load_states())
     by_cfg = {}
     for r in rows:
         by_cfg.setdefault(id(r[2]), []).append(r)          # load_states hands out one model object per configuration
-    excess, rel, skipped, total = [], [], 0, 0
+    excess, rel, skipped, total, kept_nv25 = [], [], 0, 0, 0
     for key, rs in by_cfg.items():
         m = rs[0][2]
         n = len(rs)
@@ -1295,10 +1361,14 @@ def test_solver_optimum_on_hard_states(models):
             b = too.minimise(P, P.qas.copy())
             excess.append(P.scale * (P.cost(qacc[k]) - P.cost(b)) / (1.0 + P.scale * abs(P.cost(b))))
             rel.append(float(np.max(np.abs(qacc[k] - b) / (2e-2 + 2e-3 * np.abs(b)))))
+            kept_nv25 += m.nv == 25
     excess, rel = np.array(excess), np.array(rel)
     print(f"solver optimum on hard states: {total} states, {skipped} with a contact list that differs from the fp64 one; scaled cost above the minimum / (1 + |scaled cost|): "
           f"median {np.median(excess):.1e} p90 {np.percentile(excess, 90):.1e} max {excess.max():.1e}; |qacc - a*| / (2e-2 + 2e-3 |a*|): median {np.median(rel):.2f} "
           f"p95 {np.percentile(rel, 95):.2f} max {rel.max():.2f}")
-    assert total >= 200 and skipped <= 0.25 * total
+    # the bounds are the measurements with a margin (round-5 advisor): 8 of 250 states set aside, every kept state inside the per-dof bound (worst 0.98),
+    # and the three-block states (the sparse factorisation of the 32-lane instance) must be among the kept ones
+    assert total >= 200 and skipped <= 0.05 * total, (skipped, total)
+    assert kept_nv25 >= 30, kept_nv25
     assert excess.max() < 1e-6, excess.max()
-    assert np.percentile(rel, 95) < 1.0, np.sort(rel)[-10:]
+    assert rel.max() < 1.1, np.sort(rel)[-10:]
