@@ -273,9 +273,9 @@ template <int W = 1> __device__ __forceinline__ v3 support(const Geom &G, v3 dir
         const int sub = threadIdx.x & (W - 1);
         float b = -3.0e38f;
         int idx = 0x7fffffff;
-        // the sub-group scans are only used by the persistent kernel, whose hulls stay in global memory (kin2.h: geom_cached3): say so, or the
-        // loads are compiled as flat_load (generic address: both wait counters, the LDS aperture check)
-        const __attribute__((address_space(1))) float *gverts = (const __attribute__((address_space(1))) float *)G.verts;
+        // the sub-group scans are only used by the persistent kernel: the hulls of the deepest links (the fingers) are staged in LDS, the others stay in
+        // global memory (kin2.h: geom_cached3), so these are generic (flat) loads - a global_load here measured no faster (round 4)
+        const float *gverts = (const float *)G.verts;
         auto gvert = [&](int i) { return make_float4(gverts[4 * i], gverts[4 * i + 1], gverts[4 * i + 2], 0.f); };
         for (int i0 = 0; i0 < G.nvert; i0 += 4 * W) {
             float4 q[4];

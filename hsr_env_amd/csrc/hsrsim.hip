@@ -6,6 +6,7 @@
 // k_kinematics -> k_cull + k_narrow -> k_solve_mf, optionally replayed from a captured hipGraph.
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <algorithm>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -261,7 +262,7 @@ struct hsr_batch {
 // global copies of the two constant LDS tables of the persistent kernel (same packing: kin2.h)
 __global__ void k_build_tables(DevModel m, DevState s) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < m.ngeom) geom_consts_store(m.geom_rec + 32 * i, s.geom_c + 8 * i);
+    if (i < m.ngeom) { geom_consts_store(m.geom_rec + 32 * i, s.geom_c + 8 * i); if (m.nldsv > 0 && m.geom_ldsv[i] >= 0) hull_lds_patch(s.geom_c + 8 * i, m.geom_ldsv[i]); }
     if (i < ((m.npair_pad + 7) & ~7)) {
         unsigned pk = 0;
         if (i < m.npair) {
@@ -754,6 +755,27 @@ static int batch_init(hsr_batch *b, const hsr_model *m, int n_envs) {
             const char *nf = getenv("HSR_NFB");                                // diagnostic: HSR_NFB=0 keeps the per-contact assembly
             if (nf && atoi(nf) < nfb) nfb = atoi(nf) < 0 ? 0 : atoi(nf);
             d.nfb = nfb;
+        }
+        {   // hulls staged in LDS by the instances that know their tree at compile time (their kin2 table area is free: persist.h): the hulls of the
+            // deepest links first (the fingers: what the hard envs run MPR on), smaller ones first within a link depth, while they fit
+            const int *gl = m->i32("geom_link"), *gt = m->i32("geom_type"), *ma = m->i32("geom_meshadr"), *mn = m->i32("geom_meshnum"), *lp = m->i32("link_parent");
+            std::vector<int> ldsv(std::max(d.ngeom, 1), -1), src;
+            const char *nh = getenv("HSR_LDS_HULLS");
+            const int crow = cfg_const_row(d);          // (the instance that will run: HSR_NO_CONST=1 and a model that matches no row take a generic one, whose kin2 table occupies the area)
+            if (crow >= 0 && kKin3Checks[crow].i && !(nh && strcmp(nh, "0") == 0)) {
+                const int budget = KIN2_FLOATS * d.nlink / 4;
+                auto depth = [&](int l) { int k = 0; while (l > 0) { l = lp[l]; k++; } return k; };
+                std::vector<int> order;
+                for (int g = 0; g < d.ngeom; g++) if (gt[g] == GEOM_MESH && gl[g] > 0 && mn[g] > 0) order.push_back(g);
+                std::stable_sort(order.begin(), order.end(), [&](int a, int bb) { const int da = depth(gl[a]), db = depth(gl[bb]); return da != db ? da > db : mn[a] < mn[bb]; });
+                for (int g : order) if ((int)src.size() + mn[g] <= budget) { ldsv[g] = (int)src.size(); for (int k = 0; k < mn[g]; k++) src.push_back(ma[g] + k); }
+            }
+            int *dl_; if ((rc = dalloc(b, &dl_, ldsv.size()))) return rc;
+            HIPCHK(hipMemcpy(dl_, ldsv.data(), ldsv.size() * sizeof(int), hipMemcpyHostToDevice));
+            d.geom_ldsv = dl_;
+            int *ds_; if ((rc = dalloc(b, &ds_, src.size() + 1))) return rc;
+            if (!src.empty()) HIPCHK(hipMemcpy(ds_, src.data(), src.size() * sizeof(int), hipMemcpyHostToDevice));
+            d.ldsv_src = ds_; d.nldsv = (int)src.size();
         }
         auto lds_total = [&](bool tg) { return (size_t)sizeof(float) * (b->group == 16 ? PersistLayout<16>(d.njmax, b->ds.kstride, d.npair_pad, d.nlink, d.ngeom, d.nstatic_geom, tg).total
                                                                                             : PersistLayout<32>(d.njmax, b->ds.kstride, d.npair_pad, d.nlink, d.ngeom, d.nstatic_geom, tg).total); };

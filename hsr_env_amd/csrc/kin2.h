@@ -255,7 +255,13 @@ __device__ __forceinline__ void geom_consts_store(const float *rec, float *out) 
     ks4(out, make_float4(q4.y, q4.z, q4.w, __uint_as_float(pk))); ks4(out + 4, make_float4(q6.x, q6.y, q6.z, q1.w));
 }
 // Geom from its cached world placement w (16 floats) and its constants cc (8 floats), both in LDS
-__device__ __forceinline__ Geom geom_cached3(const float *w, const float *cc, const float4 *mesh_vert4, float &rbound) {
+// hull_lds_patch: a geom whose hull the persistent kernel stages in LDS (DevModel::geom_ldsv) carries the float4 slot of its first vertex in place
+// of its mesh address, and bit 31 says so
+__device__ __forceinline__ void hull_lds_patch(float *out, int slot) {
+    const unsigned pk = __float_as_uint(out[3]);
+    out[3] = __uint_as_float((pk & 0x1fffu) | ((unsigned)slot << 13) | 0x80000000u);
+}
+__device__ __forceinline__ Geom geom_cached3(const float *w, const float *cc, const float4 *mesh_vert4, float &rbound, const float4 *ldsv = nullptr) {
     const float4 w0 = kl4(w), w1 = kl4(w + 4), w2 = kl4(w + 8), w3 = kl4(w + 12), c0 = kl4(cc), c1 = kl4(cc + 4);
     Geom G;
     G.pos = mk3(w0.x, w0.y, w0.z);
@@ -266,7 +272,7 @@ __device__ __forceinline__ Geom geom_cached3(const float *w, const float *cc, co
     G.size = mk3(c0.x, c0.y, c0.z);
     G.bh = mk3(c1.x, c1.y, c1.z);
     G.nvert = (pk >> 4) & 511;
-    G.verts = mesh_vert4 + (pk >> 13);
+    G.verts = (pk >> 31) ? ldsv + ((pk >> 13) & 0x3ffffu) : mesh_vert4 + (pk >> 13);          // (generic pointers: LDS or global)
     rbound = c1.w;
     return G;
 }

@@ -36,6 +36,9 @@ struct DevModel {
     int nfb;                          // free bodies whose six dofs (3 lin, 3 ang) form the tail of the dof vector, one after the other: their
                                       // contacts with the world are assembled per body in the Newton Hessian (solve_body.inc); 0 = none / not applicable
     const float *act_gear, *act_kp, *act_ctrlrange, *act_forcerange;
+    const int *geom_ldsv;             // [ngeom] hulls staged in LDS by the persistent kernel (persist.h: hull area): first float4 slot, or -1 (the hull stays in global memory)
+    const int *ldsv_src;              // [nldsv] vertex index in mesh_vert4 of every staged slot
+    int nldsv;
     int kin3_match;                   // host side: row + 1 of the constant instance (cfg_consts.h) whose compile-time tree tables equal this model's, 0 = none
 };
 

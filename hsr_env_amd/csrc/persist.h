@@ -177,10 +177,15 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
     __shared__ int sEnv[64 / G];                       // env index of every lane group of this workgroup (wave packing: DevState::slot_env)
     __shared__ int sTick[64 / G];                      // substeps every env of this workgroup has run since its batch was created (DevState::tick): stamps of the separation margins
     if (tid0 < nv) sDofLink[tid0] = (unsigned char)m.dof_link[tid0];
-    if (tid0 < m.nlink) kin2_store(m, tid0, lds + L.oKin + KIN2_FLOATS * tid0);
+    // the area of the per-link kinematic constants (kin2.h) is free in the instances that know their tree at compile time (kin3.h): it holds the hull
+    // vertices of the deepest links - the finger hulls that the hard envs run MPR on - so that a support scan is an LDS round trip, not a global one
+    constexpr bool KIN3_INST = Kin3Of<MT>::type::ok && EXACT;
+    const float4 *ldsv = reinterpret_cast<const float4 *>(lds + L.oKin);
+    if constexpr (KIN3_INST) { for (int i = tid0; i < m.nldsv; i += 64) reinterpret_cast<float4 *>(lds + L.oKin)[i] = m.mesh_vert4[m.ldsv_src[i]]; }
+    else if (tid0 < m.nlink) kin2_store(m, tid0, lds + L.oKin + KIN2_FLOATS * tid0);
     // geom cache: constants of every geom, placements of the static ones (world link: identity pose)
     for (int gi = tid0; gi < m.ngeom; gi += 64) {
-        if constexpr (!TG) geom_consts_store(m.geom_rec + 32 * gi, lds + L.oGeomC + 8 * gi);
+        if constexpr (!TG) { geom_consts_store(m.geom_rec + 32 * gi, lds + L.oGeomC + 8 * gi); if (KIN3_INST && m.geom_ldsv[gi] >= 0) hull_lds_patch(lds + L.oGeomC + 8 * gi, m.geom_ldsv[gi]); }
         if (gi < m.nstatic_geom) {
             m3 I3;
 #pragma unroll
@@ -399,7 +404,7 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
                     const unsigned pk = sPair[it & 0x3fff];
                     const int g1 = pk_g1(pk), g2 = pk_g2(pk);
                     float rb1, rb2;
-                    const Geom A = geom_cached3(gaddr(g1, Ei), gcc + 8 * g1, m.mesh_vert4, rb1), B = geom_cached3(gaddr(g2, Ei), gcc + 8 * g2, m.mesh_vert4, rb2);
+                    const Geom A = geom_cached3(gaddr(g1, Ei), gcc + 8 * g1, m.mesh_vert4, rb1, ldsv), B = geom_cached3(gaddr(g2, Ei), gcc + 8 * g2, m.mesh_vert4, rb2, ldsv);
                     pass = pair_cull_box_nb(A, B, rb1, rb2, skin);
                 }
                 PHASE_S(2, 28);
@@ -488,8 +493,8 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
                     const unsigned pk = sPair[p];
                     const float4 pb = pg4[2 * p + 1];
                     float rb;
-                    A = geom_cached3(gaddr(pk_g1(pk), Ei), gcc + 8 * pk_g1(pk), m.mesh_vert4, rb);
-                    B = geom_cached3(gaddr(pk_g2(pk), Ei), gcc + 8 * pk_g2(pk), m.mesh_vert4, rb);
+                    A = geom_cached3(gaddr(pk_g1(pk), Ei), gcc + 8 * pk_g1(pk), m.mesh_vert4, rb, ldsv);
+                    B = geom_cached3(gaddr(pk_g2(pk), Ei), gcc + 8 * pk_g2(pk), m.mesh_vert4, rb, ldsv);
                     o.con = s.con + (size_t)sEnv[ig] * m.nslot * 8; o.slot = (int)pb.y; o.maxcnt = (int)pb.z; o.cnt = 0;
                     cntp = reinterpret_cast<unsigned char *>(Ei + L.oCnt) + p;
                 };

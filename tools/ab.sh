@@ -1,7 +1,7 @@
 #!/bin/bash
 # A/B of build variants (tools/build_variants.py) on the GPU box: tools/ab.sh [-t "pytest -k expr"] NAME...
 # per variant: optional parity tests, bench line (cfg3), workgroup lifetimes (var_NAME_l.so), phase profile (var_NAME_t.so)
-OUT=${AB_OUT:-gpurun_out/r5}; mkdir -p $OUT
+OUT=${AB_OUT:-gpurun_out/r6}; mkdir -p $OUT
 KEXPR=""
 if [ "$1" == "-t" ]; then KEXPR="$2"; shift; shift; fi
 for v in "$@"; do
@@ -11,7 +11,7 @@ for v in "$@"; do
   [ -f hsr_env_amd/var_${v}_t.so ] && HSR_LIB=$PWD/hsr_env_amd/var_${v}_t.so python tools/block_times.py > $OUT/ab_${v}_bt.log 2>&1
   python - $v <<'PY'
 import json,sys,re,os
-v=sys.argv[1]; out=os.environ.get("AB_OUT","gpurun_out/r5")+"/"
+v=sys.argv[1]; out=os.environ.get("AB_OUT","gpurun_out/r6")+"/"
 d=json.loads(open(out+f'ab_{v}_bench.log').read().strip().splitlines()[-1])
 r=d['roofline']
 line=f"{v:12s} {d['value']/1e3:7.1f}k  kernel mean {r.get('kernel_ms_mean',0):.2f} min {r.get('kernel_ms_min',0):.2f} max {r.get('kernel_ms_max',0):.2f}"

@@ -40,7 +40,7 @@ for nm, idx in (('slowest 10', o[-10:]), ('median 10', o[nb // 2 - 5: nb // 2 + 
 if '--json' in sys.argv:
     import json
     from pathlib import Path
-    out = Path('gpurun_out/r5/block_life_%s.json' % cfg)
+    out = Path(os.environ.get('HSR_ROUND_DIR', 'gpurun_out/r6')) / ('block_life_%s.json' % cfg)
     out.parent.mkdir(parents=True, exist_ok=True)
     out.write_text(json.dumps({cfg: {"workgroups": int(nb), "p0_ms": float(np.percentile(life, 0) / 1e3), "p50_ms": float(np.median(life) / 1e3),
                                      "p90_ms": float(np.percentile(life, 90) / 1e3), "p99_ms": float(np.percentile(life, 99) / 1e3),

@@ -1,11 +1,11 @@
-"""Merge the per-configuration lifetime summaries of tools/block_life.py --json (gpurun_out/r5/block_life_<cfg>.json) into profiles/block_life.json.
+"""Merge the per-configuration lifetime summaries of tools/block_life.py --json (gpurun_out/r6/block_life_<cfg>.json, or $HSR_ROUND_DIR) into profiles/block_life.json.
 usage: python tools/collect_life.py <note>"""
-import json, sys
+import json, os, sys
 from pathlib import Path
 root = Path(__file__).resolve().parents[1]
 out = {}
 for cfg in ("cfg1", "cfg2", "cfg3", "cfg4", "cupboard"):
-    f = root / "gpurun_out" / "r5" / f"block_life_{cfg}.json"
+    f = Path(os.environ.get("HSR_ROUND_DIR", str(root / "gpurun_out" / "r6"))) / f"block_life_{cfg}.json"
     if f.exists():
         out.update(json.loads(f.read_text()))
 out["_note"] = sys.argv[1] if len(sys.argv) > 1 else ""
