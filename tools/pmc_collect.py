@@ -65,8 +65,9 @@ for k, v in wr.items():
             "write_requests_leaving_L2": nall, "of_them_full_64B_lines": n64, "bytes_full_lines": 64 * n64, "bytes_32B_partial": 32 * (nall - n64),
             "write_requests_reaching_L2": l2w,
             "reading": "one launch (the fourth after a reset).  The counters cannot name buffers; they separate two kinds.  Full 64 B lines are wave-wide rows: the "
-                       "register spills (scratch_store: 64 lanes x 4..16 B contiguous; 36 static stores in the cfg3 instance, 208 B per lane = 27 MB for the 2048 waves, "
-                       "about what the eight L2s hold, so spilled rows are evicted and come back) and the once-per-launch SoA outputs (obs / qpos / qvel / warm start: 3 MB).  "
+                       "register spills (scratch_store: 64 lanes x 4..16 B contiguous; round 6: 12 B of scratch per lane in the cfg3 instance = 1.6 MB for the 2048 waves; "
+                       "68 B in round 5, 208 B in round 3) and the once-per-launch SoA outputs (obs / qpos / qvel / warm start: 3 MB) - the rest of the full lines are runs of "
+                       "partial writes that L2 merged before they left.  "
                        "32 B partial writes are single words of env-strided arrays - DevState::sepax / septick (separation margin + stamp of every convex item, "
                        "two words per item and substep, 19 MB footprint), the per-pair contact counts - and the 32 B contact records (DevState::con, 2 x float4 per contact).  "
                        "Requests reaching L2 against requests leaving it = how much of the store stream L2 absorbs."}
