@@ -285,6 +285,11 @@ class BatchSim:
     def is_persistent(self) -> bool:
         return bool(self._L.hsr_batch_is_persistent(self._b))
 
+    def kernel_flags(self) -> int:
+        """hsr_batch_is_persistent's bit mask: 1 = whole env-step in the persistent kernel, 2 = the instance carries the model's scalars as
+        compile-time constants, 4 = and its kinematic tree (csrc/kin3.h)."""
+        return int(self._L.hsr_batch_is_persistent(self._b))
+
     def set_debug(self, on):
         """Also store the contact counts / solver counters of each env's last substep during step() (persistent kernel).
         `on` may be a bit mask: 1 = store, 2 / 4 = test hooks (J v per contact / PSD-majorant Newton steps), include/hsrsim.h."""

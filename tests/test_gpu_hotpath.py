@@ -102,6 +102,7 @@ def test_setxml_model_single_substep(models):
     q, v, ctrl = random_states(models["cfg3"], n, rng)      # cfg3's ranges (the unlimited actuator has none to sample from)
     pre = oracle_rollout(m, q, v, ctrl, 60)
     sim = hs.BatchSim(m, n)
+    assert sim.kernel_flags() == 7          # the setters change friction and an actuator limit, not the tree: cfg3's constant instance (scalars + tree tables) serves it
     sim.set_debug(True)
     sim.set_warmstart(np.array([s.qacc_warmstart for s in pre]))
     sim.set_state(np.zeros(n), np.array([s.qpos for s in pre]), np.array([s.qvel for s in pre]))
@@ -689,7 +690,9 @@ def test_step_outputs_written_by_the_persistent_kernel(models):
 def test_constant_instances_equal_the_generic_ones(models, cfg, monkeypatch):
     """The reference configurations run kernel instances whose scalar model fields are compile-time constants (cfg_consts.h);
     HSR_NO_CONST=1 runs the same model through the generic instance (fields read from memory).  Same algorithm, same inputs: the
-    results agree to rounding (constant folding may evaluate a reciprocal exactly where the hardware instruction is 1 ulp off)."""
+    results agree to rounding (constant folding may evaluate a reciprocal exactly where the hardware instruction is 1 ulp off; round 6: the constant
+    instances also compute kinematics, inertia and bias force as straight-line code on their compile-time tree - csrc/kin3.h - where the generic ones walk
+    the tree tables: another summation order, same quantities)."""
     m = models[cfg]
     n = 128
     rng = np.random.default_rng(21)
@@ -699,6 +702,7 @@ def test_constant_instances_equal_the_generic_ones(models, cfg, monkeypatch):
         monkeypatch.setenv("HSR_NO_CONST", nc)
         sim = hs.BatchSim(m, n)
         assert sim.is_persistent()
+        assert sim.kernel_flags() == (7 if nc == "0" else 1), sim.kernel_flags()          # constants + compile-time tree (kin3.h) against the generic instance
         sim.set_state(np.zeros(n), q, v)
         outs.append(sim.step(ctrl, 20)[0].copy())
         sim.close()
