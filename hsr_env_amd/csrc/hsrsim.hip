@@ -740,6 +740,14 @@ static int batch_init(hsr_batch *b, const hsr_model *m, int n_envs) {
     }
     {
         d.kin3_match = kin3_matching_row(m);
+        if (d.kin3_match) {      // kin3.h stages 12 floats per dof and the robot's block of M in the row-scalar region of an env (Kin3Stage): it has to fit
+            const int *lf = m->i32("link_free"), *dl = m->i32("dof_link");
+            int nrd = 0;
+            for (int k = 0; k < d.nv; k++) nrd += lf[dl[k]] ? 0 : 1;
+            const int stage = 12 * d.nv + ((nrd + 3) & ~3) * nrd;
+            const int region = b->group == 16 ? PersistLayout<16>(d.njmax, b->ds.kstride, d.npair_pad, d.nlink, d.ngeom, d.nstatic_geom).oCnt : PersistLayout<32>(d.njmax, b->ds.kstride, d.npair_pad, d.nlink, d.ngeom, d.nstatic_geom).oCnt;
+            if (stage > region) d.kin3_match = 0;
+        }
         {   // (before an instance is chosen: the constant instances are matched on nfb too)
             // trailing free bodies: link l owns exactly the dofs [nv - 6 (k + 1), nv - 6 k), lin then ang
             const int *dn = m->i32("link_dofnum"), *lf = m->i32("link_free"), *da = m->i32("link_dofadr"), *dt = m->i32("dof_type"), *dl = m->i32("dof_link");
