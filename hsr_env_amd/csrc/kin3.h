@@ -95,7 +95,7 @@ template <class KD> struct Kin3Stage { static constexpr int RS = (KD::NRD + 3) &
 template <int G> struct Kin3Lane { v3 a, l, n; float bias, Mdiag; float Mrow[G]; };
 
 template <class KD, int G, int NK>
-__device__ __forceinline__ void kin3_run(int c, float gravz, float *qposL, const float *qvelL, float *poseL, float *recL, float *st) {
+__device__ __forceinline__ void kin3_run(int c, float gravz, float *qposL, const float *qvelL, float *poseL, float *recL, float *st, float *lkL, const float *link_com, const float *link_inertia, const float *link_mass) {
     using namespace k3;
     constexpr int NL = KD::NL, NV = KD::NV, RD0 = KD::RD0, NRD = KD::NRD;
     typedef Kin3Stage<KD> ST;
@@ -153,6 +153,12 @@ __device__ __forceinline__ void kin3_run(int c, float gravz, float *qposL, const
     }
     // ---- robot: coordinates and velocities of its scalar joints (every lane reads all of them: broadcast reads)
     const bool lane0 = c == 0;
+    // lane = link for the link dynamics below: the constants of this lane's link are fetched now (global memory, L2-resident) and used after the recursion
+    const int lc = c < NL ? c : 0;          // (the fetch below is dead code in the instances without LANE_DYN)
+    typedef const __attribute__((address_space(1))) float *gcf_;
+    const gcf_ gli = (gcf_)link_inertia + 6 * lc, gcm = (gcf_)link_com + 3 * lc;
+    const float kI[6] = {gli[0], gli[1], gli[2], gli[3], gli[4], gli[5]};
+    const float kcom[3] = {gcm[0], gcm[1], gcm[2]}, kmass = ((gcf_)link_mass)[lc];
     float Q[NRD], QD[NRD];
     static_for<0, NRD>([&](auto kc) { constexpr int k = decltype(kc)::value; Q[k] = qposL[KD::dqadr[RD0 + k]]; QD[k] = qvelL[RD0 + k]; });
     m3 Rw[NL];
@@ -164,6 +170,24 @@ __device__ __forceinline__ void kin3_run(int c, float gravz, float *qposL, const
     for (int i = 0; i < 9; i++) Rw[0].a[i] = (i % 4 == 0) ? 1.f : 0.f;
     Pw[0] = mk3(0, 0, 0); Ww[0] = mk3(0, 0, 0); VOw[0] = mk3(0, 0, 0); ALw[0] = mk3(0, 0, 0); AOw[0] = mk3(0, 0, 0);
     if (lane0) { pose_store(poseL, Rw[0], Pw[0]); ks4(recL, make_float4(0, 0, 0, 0)); ks4(recL + 4, make_float4(0, 0, 0, 0)); }
+    // LANE_DYN: the chain has hinges - the links' world inertias and wrenches are worth a lane-parallel pass (lane = link, through LDS); a chain of slides only (cfg1 / cfg2:
+    // one link, identity orientation) folds to constants in the redundant form, which is then cheaper than the detour
+    constexpr bool LANE_DYN = [] { for (int k = 0; k < NRD; k++) if (KD::dtype[RD0 + k] == DOF_HINGE) return true; return false; }();
+    // what link l adds to the sums of every dof that moves it (solve_body.inc, inertia phase):
+    //   V = sum m jp_c(l), TU = sum I a_c + (com - n_c) x (m jp_c(l)), bias = sum jp_c(l) . F + a_c . N,   jp_c(l) = lin_c + a_c x (com - n_c)
+    auto accumulate = [&](auto lc_, const v3 com, const m3 &I, const v3 F, const v3 Nt) {
+        constexpr int l = decltype(lc_)::value;
+        static_for<0, NRD>([&](auto kc) {
+            constexpr int kr = decltype(kc)::value;
+            if constexpr (dof_above_link<KD>(RD0 + kr, l)) {
+                const v3 rr = k_sub(com, ANC[kr]);
+                const v3 jpc = k_add(LIN[kr], k_cross(ANG[kr], rr));
+                const v3 v = k_scl(jpc, KD::lmass[l]);
+                Bc[kr] = ca(Bc[kr], ca(k_dot(jpc, F), k_dot(ANG[kr], Nt)));
+                Vc[kr] = k_add(Vc[kr], v); TUc[kr] = k_add(TUc[kr], k_add(k_mulmv(I, ANG[kr]), k_cross(rr, v)));
+            }
+        });
+    };
     static_for<1, NL>([&](auto lc) {
         constexpr int l = decltype(lc)::value;
         if constexpr (!KD::isfree[l]) {
@@ -219,34 +243,63 @@ __device__ __forceinline__ void kin3_run(int c, float gravz, float *qposL, const
                 }
             });
             Ww[l] = w; VOw[l] = vo; ALw[l] = al; AOw[l] = ao;
-            if (lane0) {      // one lane of the env stores the link's pose and velocity (geom placement, goal test, outputs)
+            if (lane0) {      // one lane of the env stores the link's pose and velocity state (geom placement, goal test, outputs; the link dynamics below)
                 pose_store(poseL + 12 * l, mat, pos);
-                ks4(recL + 12 * l, make_float4(w.x, w.y, w.z, vo.x)); ks4(recL + 12 * l + 4, make_float4(vo.y, vo.z, 0.f, 0.f));
+                ks4(recL + 12 * l, make_float4(w.x, w.y, w.z, vo.x)); ks4(recL + 12 * l + 4, make_float4(vo.y, vo.z, al.x, al.y)); ks4(recL + 12 * l + 8, make_float4(al.z, ao.x, ao.y, ao.z));
             }
-            // world inertia, com and the wrench of mj_rne: F = m (a(com) - gravity), N = I al + w x I w
-            m3 Il;
-            Il.a[0] = KD::linr[l][0]; Il.a[1] = KD::linr[l][3]; Il.a[2] = KD::linr[l][4]; Il.a[3] = KD::linr[l][3]; Il.a[4] = KD::linr[l][1]; Il.a[5] = KD::linr[l][5];
-            Il.a[6] = KD::linr[l][4]; Il.a[7] = KD::linr[l][5]; Il.a[8] = KD::linr[l][2];
-            const m3 I = k_mulmm(k_mulmm(mat, Il), k_transpose(mat));
-            const v3 rcm = k_mulmv(mat, K3C3(lcom, l)), com = k_add(pos, rcm);
-            const v3 acom = k_add(k_add(ao, k_cross(al, rcm)), k_cross(w, k_cross(w, rcm)));
-            const v3 F = k_scl(k_sub(acom, mk3(0.f, 0.f, gravz)), KD::lmass[l]);
-            const v3 Nt = k_add(k_mulmv(I, al), k_cross(w, k_mulmv(I, w)));
-            // ... and what the link adds to the sums of every dof that moves it (solve_body.inc, inertia phase):
-            //   V = sum m jp_c(l), TU = sum I a_c + (com - n_c) x (m jp_c(l)), bias = sum jp_c(l) . F + a_c . N,   jp_c(l) = lin_c + a_c x (com - n_c)
-            static_for<0, NRD>([&](auto kc) {
-                constexpr int kr = decltype(kc)::value;
-                if constexpr (dof_above_link<KD>(RD0 + kr, l)) {
-                    const v3 rr = k_sub(com, ANC[kr]);
-                    const v3 jpc = k_add(LIN[kr], k_cross(ANG[kr], rr));
-                    const v3 v = k_scl(jpc, KD::lmass[l]);
-                    Bc[kr] = ca(Bc[kr], ca(k_dot(jpc, F), k_dot(ANG[kr], Nt)));
-                    Vc[kr] = k_add(Vc[kr], v); TUc[kr] = k_add(TUc[kr], k_add(k_mulmv(I, ANG[kr]), k_cross(rr, v)));
-                }
-            });
+            if constexpr (!LANE_DYN) {      // world inertia, com and the wrench of mj_rne, F = m (a(com) - gravity), N = I al + w x I w: every lane, constants folded
+                m3 Il;
+                Il.a[0] = KD::linr[l][0]; Il.a[1] = KD::linr[l][3]; Il.a[2] = KD::linr[l][4]; Il.a[3] = KD::linr[l][3]; Il.a[4] = KD::linr[l][1]; Il.a[5] = KD::linr[l][5];
+                Il.a[6] = KD::linr[l][4]; Il.a[7] = KD::linr[l][5]; Il.a[8] = KD::linr[l][2];
+                const m3 I = k_mulmm(k_mulmm(mat, Il), k_transpose(mat));
+                const v3 rcm = k_mulmv(mat, K3C3(lcom, l)), com = k_add(pos, rcm);
+                const v3 acom = k_add(k_add(ao, k_cross(al, rcm)), k_cross(w, k_cross(w, rcm)));
+                const v3 F = k_scl(k_sub(acom, mk3(0.f, 0.f, gravz)), KD::lmass[l]);
+                const v3 Nt = k_add(k_mulmv(I, al), k_cross(w, k_mulmv(I, w)));
+                accumulate(lc, com, I, F, Nt);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    });
+    if constexpr (LANE_DYN) {
+    wave_sync();
+    // ---- link dynamics, lane = link (every link at once): world inertia, com and the wrench of mj_rne, F = m (a(com) - gravity), N = I al + w x I w, from the
+    // link's pose and velocity state (LDS) and its constants (fetched above); 16 floats per link: com 3, I (xx yy zz xy xz yz), F 3, N 3, -
+    {
+        m3 Rl; v3 pl;
+        pose_load(poseL + 12 * lc, Rl, pl);
+        const float4 r0 = kl4(recL + 12 * lc), r1 = kl4(recL + 12 * lc + 4), r2 = kl4(recL + 12 * lc + 8);
+        const v3 wl = mk3(r0.x, r0.y, r0.z), all = mk3(r1.z, r1.w, r2.x), aol = mk3(r2.y, r2.z, r2.w);
+        m3 Il;
+        Il.a[0] = kI[0]; Il.a[1] = kI[3]; Il.a[2] = kI[4]; Il.a[3] = kI[3]; Il.a[4] = kI[1]; Il.a[5] = kI[5]; Il.a[6] = kI[4]; Il.a[7] = kI[5]; Il.a[8] = kI[2];
+        const m3 A = ::mulmm(Rl, Il);
+        float Iw[6];          // the six distinct entries of A R^T
+        Iw[0] = A.a[0] * Rl.a[0] + A.a[1] * Rl.a[1] + A.a[2] * Rl.a[2]; Iw[1] = A.a[3] * Rl.a[3] + A.a[4] * Rl.a[4] + A.a[5] * Rl.a[5]; Iw[2] = A.a[6] * Rl.a[6] + A.a[7] * Rl.a[7] + A.a[8] * Rl.a[8];
+        Iw[3] = A.a[0] * Rl.a[3] + A.a[1] * Rl.a[4] + A.a[2] * Rl.a[5]; Iw[4] = A.a[0] * Rl.a[6] + A.a[1] * Rl.a[7] + A.a[2] * Rl.a[8]; Iw[5] = A.a[3] * Rl.a[6] + A.a[4] * Rl.a[7] + A.a[5] * Rl.a[8];
+        auto Imul = [&](v3 x) { return mk3(Iw[0] * x.x + Iw[3] * x.y + Iw[4] * x.z, Iw[3] * x.x + Iw[1] * x.y + Iw[5] * x.z, Iw[4] * x.x + Iw[5] * x.y + Iw[2] * x.z); };
+        const v3 rcm = ::mulmv(Rl, mk3(kcom[0], kcom[1], kcom[2])), com = pl + rcm;
+        const v3 acom = aol + ::cross(all, rcm) + ::cross(wl, ::cross(wl, rcm));
+        const v3 F = (acom - mk3(0.f, 0.f, gravz)) * kmass;
+        const v3 Nt = Imul(all) + ::cross(wl, Imul(wl));
+        if (c > 0 && c < NL) {
+            float *o = lkL + 16 * c;
+            ks4(o, make_float4(com.x, com.y, com.z, Iw[0])); ks4(o + 4, make_float4(Iw[1], Iw[2], Iw[3], Iw[4])); ks4(o + 8, make_float4(Iw[5], F.x, F.y, F.z)); ks4(o + 12, make_float4(Nt.x, Nt.y, Nt.z, 0.f));
+        }
+    }
+    wave_sync();
+    // ---- what every link adds to the sums of every dof that moves it (every lane, same values)
+    static_for<1, NL>([&](auto lc_) {
+        constexpr int l = decltype(lc_)::value;
+        if constexpr (!KD::isfree[l]) {
+            const float4 q0 = kl4(lkL + 16 * l), q1 = kl4(lkL + 16 * l + 4), q2 = kl4(lkL + 16 * l + 8), q3 = kl4(lkL + 16 * l + 12);
+            const v3 com = mk3(q0.x, q0.y, q0.z), F = mk3(q2.y, q2.z, q2.w), Nt = mk3(q3.x, q3.y, q3.z);
+            m3 I;
+            I.a[0] = q0.w; I.a[4] = q1.x; I.a[8] = q1.y; I.a[1] = I.a[3] = q1.z; I.a[2] = I.a[6] = q1.w; I.a[5] = I.a[7] = q2.x;
+            accumulate(lc_, com, I, F, Nt);
             __builtin_amdgcn_sched_barrier(0);          // (one link at a time: a scheduler that interleaves the links keeps all their temporaries alive)
         }
     });
+    }
     // ---- the dof records and the robot's block of M: M[c][k] = lin_k . V_c + a_k . (TU_c + (n_c - n_k) x V_c) for k = c and the dofs above it;
     // row c goes out as whole rows (entries of unrelated dofs are zero), the mirrored entries M[k][c] one by one
     static_for<0, NRD>([&](auto cc) {

@@ -297,7 +297,7 @@ __global__ void __launch_bounds__(64, 2) k_env_step_mf(const DevModel *__restric
         constexpr bool KIN3 = KD::ok && EXACT;
         if constexpr (KIN3) {
 #ifndef HSR_K3_NORUN
-            kin3_run<KD, G, NK>(c, m.gravz, qposL, qvelL, poseL, recL, kAng);
+            kin3_run<KD, G, NK>(c, m.gravz, qposL, qvelL, poseL, recL, kAng, qvelL + G, m.link_com, m.link_inertia, m.link_mass);          // (link records where the geom placements go afterwards)
 #endif
             wave_sync();
             PHASE_K(26);
